@@ -1,0 +1,31 @@
+# Build everything in-tree (built libraries are git-ignored but travel to the GPU box).
+#   make            -> host scene lib, HIP core, oracle
+#   make oracle     -> oracle only (test infrastructure)
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+PKG     := ray-tracer_amd
+LIBDIR  := $(PKG)/lib
+CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
+# -ffp-contract=off: the closest-hit arithmetic must be evaluated exactly as written
+# (no FMA) so primitive ids match the oracle bit for bit.
+HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Iinclude
+
+all: $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so oracle
+
+$(LIBDIR)/librt_scene.so: $(PKG)/csrc/host/rt_scene.cpp include/rt_scene.h include/rt.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $<
+
+$(LIBDIR)/librt_amd.so: $(PKG)/csrc/rt_core.hip $(wildcard $(PKG)/csrc/*.h) include/rt.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+oracle: oracle/lib/librt_oracle.so
+oracle/lib/librt_oracle.so: oracle/rt_oracle.cpp include/rt.h
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIBDIR) oracle/lib
+
+.PHONY: all oracle clean

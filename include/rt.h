@@ -1,0 +1,258 @@
+/*
+ * rt.h -- C-ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * Drop-in boundary for the render call of EricWittrock/Ray-Tracer: the kernel
+ * launch `render2<<<grid,block>>>(...)` (reference src/main.cu:472-482), the
+ * uploads that feed it (src/main.cu:418-460) and the readback after it
+ * (src/main.cu:500-501).  Every array crosses this boundary in the
+ * reference's own layout (25-float triangle records, 40-byte BVH nodes,
+ * 48-byte materials, one float RGB texture pool, int light list); the
+ * library converts them to its gfx950 layouts at upload.
+ *
+ * Plain C: POD structs, pointers and sizes only.  Every function returns
+ * RT_OK (0) or a negative rt_status; nothing exits or throws across the ABI
+ * (the reference prints and continues, src/main.cu:484-492).
+ *
+ * A context is bound to one HIP device and is not thread-safe.  There is no
+ * CPU fallback: without a usable HIP device rt_create fails.
+ */
+#ifndef RT_H_
+#define RT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------- */
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument / malformed scene              */
+    RT_ERR_DEVICE = -2,    /* HIP error (message in rt_last_error)        */
+    RT_ERR_NO_SCENE = -3,  /* render/trace before rt_upload_scene         */
+    RT_ERR_LIMIT = -4,     /* scene exceeds a built-in limit (BVH depth…) */
+    RT_ERR_NOMEM = -5
+} rt_status;
+
+/* ---- reference layouts -------------------------------------------------- */
+
+/* BVH::BVHNode, reference src/BVHcreator.h:23-34 (40 bytes, AoS).
+ * child_a == -1 marks a leaf; tri_offs / tri_len are FLOAT offsets/lengths
+ * into the triangle array (25 floats per triangle). */
+typedef struct rt_bvh_node {
+    float bbox_min[3];
+    float bbox_max[3];
+    int32_t child_a;
+    int32_t child_b;
+    int32_t tri_offs;
+    int32_t tri_len;
+} rt_bvh_node;
+
+/* class Material, reference src/material.h:9-22 (48 bytes with the natural
+ * padding of the original: char type at 0, int color at 4, ... u16 width at
+ * 32, u16 height at 34, pointer at 40).  The pointer member is never
+ * dereferenced by the reference kernel and is ignored here. */
+typedef struct rt_material {
+    int8_t type;
+    int8_t pad0_[3];
+    int32_t color;          /* 0xRRGGBB, vec3.h:111-123 */
+    float p1, p2, p3;
+    int32_t image_offset[3]; /* float offsets into the texture pool, -1 = none */
+    uint16_t image_width;
+    uint16_t image_height;
+    int32_t pad1_;
+    uint64_t textures_unused;
+} rt_material;
+
+/* class SceneConfigs, reference src/sceneConfigs.h:4-18 (80 bytes). */
+typedef struct rt_camera {
+    int32_t width;
+    int32_t height;
+    int32_t num_samples;
+    float focal_length;
+    float aperture;
+    float focus_distance;
+    float pos[3];
+    float rot[3];
+    float vel[3];
+    float ang_vel[3];
+    int32_t env_width;   /* 0 = no environment map (constant background) */
+    int32_t env_height;
+} rt_camera;
+
+#define RT_TRI_FLOATS 25 /* model.h:135-162: v0 v1 v2 n0 n1 n2 uv0 uv1 uv2 matId+0.001 */
+
+/* The argument list of render2 (main.cu:155) as host arrays.
+ * `tris` starts with the optional sphere prefix of sceneParser.cpp:443-453:
+ * when n_spheres > 0 the first 1 + 5*n_spheres floats are
+ * [N+0.0001, (x,y,z,r,mat+0.0001) x N] and triangle records follow; BVH
+ * tri_offs and light_tris are relative to the first triangle record
+ * (main.cu:161-168).  n_tri_floats counts the triangle floats only. */
+typedef struct rt_scene_desc {
+    const float* tris;
+    size_t n_tri_floats;
+    int32_t n_spheres;
+    const rt_bvh_node* nodes;
+    int32_t n_nodes;
+    const rt_material* mats;
+    size_t n_mats;
+    const float* textures; /* env map (if any) at offset 0, sceneParser.cpp:482-495 */
+    size_t n_tex_floats;
+    const int32_t* light_tris; /* float offsets of importance-sampled triangles */
+    int32_t n_light_tris;
+} rt_scene_desc;
+
+/* ---- render parameters -------------------------------------------------- */
+
+/* Runtime versions of the compile-time switches of reference src/config.h. */
+enum {
+    RT_F_SKYBOX = 1 << 0,       /* ENABLE_SKYBOX        config.h:5  */
+    RT_F_ANTIALIAS = 1 << 1,    /* ENABLE_ANTIALIASING  config.h:11 */
+    RT_F_DEFOCUS = 1 << 2,      /* ENABLE_DEFOCUS_BLUR  config.h:10 */
+    RT_F_BVH = 1 << 3,          /* ENABLE_BVH           config.h:16 (off = brute force, main.cu:285-301) */
+    RT_F_SPHERES = 1 << 4,      /* ENABLE_SPHERES       config.h:13 */
+    RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9  (reserved, rejected) */
+    RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14 (reserved, rejected) */
+    RT_F_STATS = 1 << 8,        /* count rays / node visits / triangle tests */
+    RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
+};
+
+typedef struct rt_render_params {
+    rt_camera cam;        /* cam.num_samples is NOT used here; see sample_count */
+    int32_t max_bounces;  /* MAX_BOUNCES, config.h:3 (default 6) */
+    uint32_t flags;       /* RT_F_* */
+    uint32_t seed;        /* reference: 37811 (main.cu:171) */
+    int32_t sample_begin; /* first sample index rendered by this call */
+    int32_t sample_count; /* samples added to the accumulators by this call */
+    /* Tile-row partition: image rows are cut into bands of band_rows rows;
+     * this call renders band b iff b % band_stride == band_index.  The
+     * accumulator then holds only those rows, packed band after band.
+     * band_stride <= 1 renders the whole image. */
+    int32_t band_rows;
+    int32_t band_stride;
+    int32_t band_index;
+    float background[3];       /* BACKGROUND_COLOR config.h:7 (1,1,0.05) */
+    float background_brightness; /* BACKGROUND_BRIGHTNESS config.h:6 (0.5) */
+} rt_render_params;
+
+typedef struct rt_render_stats {
+    double kernel_ms;       /* HIP-event time of the render kernel(s) of this call */
+    uint64_t paths;         /* camera samples started */
+    uint64_t rays;          /* closest-hit queries (primary + continued bounces), main.cu:220 */
+    uint64_t inner_visits;  /* inner nodes popped, main.cu:265-279 */
+    uint64_t leaf_visits;   /* leaves popped, main.cu:246-264 */
+    uint64_t tri_tests;     /* rayTriangleIntersect calls, main.cu:256 */
+    uint64_t hits;          /* bounces that hit a triangle or sphere */
+    uint64_t texel_fetches; /* material texel fetches + env fetches */
+    uint64_t light_tests;   /* ImportanceTri::pdf_value calls, material.h:315-323 */
+} rt_render_stats;
+
+enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };
+
+typedef struct rt_context rt_context;
+
+/* ---- entry points ------------------------------------------------------- */
+
+/* Replaces the device set-up of main(): src/main.cu:418-420.  device_id < 0
+ * uses the current HIP device. */
+int rt_create(rt_context** out, int device_id);
+void rt_destroy(rt_context* ctx);
+const char* rt_last_error(const rt_context* ctx);
+
+/* Replaces the six cudaMalloc+cudaMemcpy uploads, src/main.cu:418-460.
+ * Copies and converts; the caller keeps ownership of every host array. May
+ * be called again to replace the scene. */
+int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
+
+/* Replaces the launch + sync of render2, src/main.cu:463-492.  Adds
+ * params->sample_count samples per pixel to the raw-sum accumulators
+ * (re-entrant: progressive batches and sample slices).  Blocking.
+ * stats may be NULL. */
+int rt_render(rt_context* ctx, const rt_render_params* params, rt_render_stats* stats);
+
+/* Replaces the D2H copy src/main.cu:500-501 (and, with RT_READ_TONEMAPPED,
+ * the `/numSamples` + toneMap of main.cu:392-406 that the reference does
+ * inside the kernel).  n_floats must equal rows*width*3 of the last render. */
+int rt_readback(rt_context* ctx, float* rgb, size_t n_floats, int mode);
+
+/* Zero the accumulators and the sample counter. */
+int rt_reset_accum(rt_context* ctx);
+
+/* Use caller-owned DEVICE memory (n_floats >= rows*width*3) as the raw-sum
+ * accumulator, so that the host layer can run its RCCL reduce/gather on it
+ * directly.  dev_ptr == NULL returns to the internal buffer.  No reference
+ * counterpart (the reference is single-GPU). */
+int rt_bind_accum(rt_context* ctx, float* dev_ptr, size_t n_floats);
+
+/* Tell the context how many samples the bound accumulator now holds (after
+ * an external sum-reduce of sample slices). */
+int rt_set_sample_count(rt_context* ctx, int64_t samples);
+
+/* Launch on this hipStream_t instead of the context's own stream. */
+int rt_set_stream(rt_context* ctx, void* hip_stream);
+
+/* Resolve the accumulators into device memory (dev_out: rows*width*3 floats)
+ * with the given RT_READ_* mode; no host copy. */
+int rt_resolve_device(rt_context* ctx, float* dev_out, size_t n_floats, int mode);
+
+/* Test hook: closest hit of explicit rays through the traversal of
+ * main.cu:221-301.  org_dir = n x 6 floats (origin, direction) on the host.
+ * prim_id = hitTriIndex/25 or -1; t = |hitPos - origin| (sqrt of the
+ * reference's closest-hit metric, main.cu:257), hit_pos = 3 floats,
+ * normal3 = interpolated shading normal (material.h:51-52).  Output pointers
+ * may be NULL.  counts (may be NULL) = per-ray {inner, leaf, tri} visit
+ * counts, 3 x int32 per ray. */
+int rt_trace_rays(rt_context* ctx, const float* org_dir, size_t n, uint32_t flags,
+                  int32_t* prim_id, float* t, float* hit_pos, float* normal3, int32_t* counts);
+
+/* Test hook: evaluate device-side primitives on n host records.
+ * Each op reads `in_stride` floats and writes `out_stride` floats per record
+ * (layouts in DESIGN.md "device unit ops"). */
+enum {
+    RT_OP_TRI_INTERSECT = 1, /* main.cu:41-70      in 15: o d v0 v1 v2      out 4: hit pos           */
+    RT_OP_AABB_DIST = 2,     /* main.cu:73-117     in 12: o d min max       out 1                    */
+    RT_OP_SPHERE = 3,        /* sphere.h:30-46     in 10: o d c r           out 7: hit pos normal    */
+    RT_OP_FLOOR = 4,         /* floor.h:8-21       in 7:  o d elevation     out 7: hit pos normal    */
+    RT_OP_ITRI_PDF = 5,      /* importanceTri.h:67 in 15: o d p1 p2 p3      out 1                    */
+    RT_OP_ITRI_SAMPLE = 6,   /* importanceTri.h:79 in 14: o r1 r2 p1 p2 p3  out 3                    */
+    RT_OP_ATTRACTOR_PDF = 7, /* rayAttractor.h:39  in 15: o d pos u v       out 1                    */
+    RT_OP_ATTRACTOR_SAMPLE = 8, /* rayAttractor.h:50 in 14: o r1 r2 pos u v out 3                    */
+    RT_OP_TONEMAP = 9,       /* main.cu:23-38      in 3                     out 3                    */
+    RT_OP_RNG = 10,          /* counter RNG        in 4 (as u32 bits: seed pixel sample dim) out 4 (u32 bits) */
+    RT_OP_ENV_INDEX = 11,    /* main.cu:376-382    in 5: d envW envH        out 1 (int bits)         */
+    RT_OP_CAMERA_RAY = 12    /* main.cu:173-217    in 3 (u32 bits: x y sample), camera/flags/seed from params: out 6 */
+};
+/* params is only read by RT_OP_CAMERA_RAY (may be NULL otherwise). */
+int rt_debug_op(rt_context* ctx, int op, const float* in, size_t n, float* out,
+                const rt_render_params* params);
+
+/* Test hook: one Material::reflect (material.h:41-106) per record against the
+ * uploaded scene.  in = 16 floats per record:
+ *   o(3) d(3) throughput(3) refractiveIndex hitPos(3) triId(int bits)
+ *   rngKey: pixel(u32 bits) sample(u32 bits)   [bounce = 0, params->seed]
+ * out = 16 floats: o(3) d(3, before the kernel's renormalise main.cu:361)
+ *   throughput(3) emission(3) refractiveIndex volumeDensity terminated(int bits) pad */
+int rt_shade_hits(rt_context* ctx, const float* in, size_t n, uint32_t seed, float* out);
+
+/* ---- counter-based RNG (replaces cuRAND XORWOW, main.cu:170-171) ---------
+ * draw(seed, pixel, sample, dim) = Philox4x32-10(
+ *     counter = {pixel, sample, dim >> 2, RT_RNG_TAG}, key = {seed, RT_RNG_KEY1})[dim & 3]
+ * pixel = x + y*width in full-image coordinates (main.cu:171), sample = absolute
+ * sample index.  uniform = ((draw >> 8) + 1) * 2^-24 in (0,1] like curand_uniform.
+ * normal  = sqrtf(-2 logf(u_a)) * cosf(RT_TWO_PI_F * u_b) from two consecutive dims.
+ * Dimensions: 0 animation time (main.cu:179), 1-2 anti-alias jitter (:200-201),
+ * 4-5 lens theta, r (:120-121); bounce j owns dims 8+8j .. 15+8j, consumed in
+ * the reference's call order inside Material::reflect / Sphere::hitSphere. */
+#define RT_RNG_TAG 0x52544131u
+#define RT_RNG_KEY1 0x9E3779B9u
+#define RT_RNG_DIM_CAMERA 0
+#define RT_RNG_DIM_LENS 4
+#define RT_RNG_DIM_BOUNCE0 8
+#define RT_RNG_DIMS_PER_BOUNCE 8
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H_ */

@@ -1,0 +1,395 @@
+"""ray-tracer_amd -- thin ctypes plumbing over the C-ABI of the MI355X path-tracing core.
+
+The product is the two shared libraries built from ``csrc/``:
+
+* ``lib/librt_scene.so`` -- host scene assembly (include/rt_scene.h; reference
+  src/sceneParser.cpp, src/model.h, src/BVHcreator.cpp, src/noiseTexture.cpp, src/texture.cpp)
+* ``lib/librt_amd.so``   -- the HIP render core (include/rt.h; reference src/main.cu:155-407,
+  src/material.h and the headers they call)
+
+This module only mirrors the structs of ``include/rt.h`` and forwards calls.  There is
+no CPU fallback: if ``librt_amd.so`` is missing or no HIP device is usable, the
+constructors raise.
+
+(The directory name has a hyphen, so import it through ``importlib`` -- see
+``__graft_entry__.load_package()``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_DIR = os.path.join(_HERE, "lib")
+ASSET_DIR = os.path.join(REPO_ROOT, "assets")
+SCENE_DIR = os.path.join(REPO_ROOT, "scenes")
+
+# ----------------------------------------------------------------------------- structs (include/rt.h)
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3), ("child_a", C.c_int32),
+                ("child_b", C.c_int32), ("tri_offs", C.c_int32), ("tri_len", C.c_int32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int8), ("pad0_", C.c_int8 * 3), ("color", C.c_int32), ("p1", C.c_float),
+                ("p2", C.c_float), ("p3", C.c_float), ("image_offset", C.c_int32 * 3),
+                ("image_width", C.c_uint16), ("image_height", C.c_uint16), ("pad1_", C.c_int32),
+                ("textures_unused", C.c_uint64)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_samples", C.c_int32),
+                ("focal_length", C.c_float), ("aperture", C.c_float), ("focus_distance", C.c_float),
+                ("pos", C.c_float * 3), ("rot", C.c_float * 3), ("vel", C.c_float * 3),
+                ("ang_vel", C.c_float * 3), ("env_width", C.c_int32), ("env_height", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("tris", C.POINTER(C.c_float)), ("n_tri_floats", C.c_size_t), ("n_spheres", C.c_int32),
+                ("nodes", C.POINTER(BvhNode)), ("n_nodes", C.c_int32), ("mats", C.POINTER(Material)),
+                ("n_mats", C.c_size_t), ("textures", C.POINTER(C.c_float)), ("n_tex_floats", C.c_size_t),
+                ("light_tris", C.POINTER(C.c_int32)), ("n_light_tris", C.c_int32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("cam", Camera), ("max_bounces", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint32),
+                ("sample_begin", C.c_int32), ("sample_count", C.c_int32), ("band_rows", C.c_int32),
+                ("band_stride", C.c_int32), ("band_index", C.c_int32), ("background", C.c_float * 3),
+                ("background_brightness", C.c_float)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("rays", C.c_uint64),
+                ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+assert C.sizeof(BvhNode) == 40 and C.sizeof(Material) == 48 and C.sizeof(Camera) == 80
+
+F_SKYBOX, F_ANTIALIAS, F_DEFOCUS, F_BVH, F_SPHERES, F_VOLUME, F_RAYMARCH = 1, 2, 4, 8, 16, 32, 64
+F_STATS = 1 << 8
+F_DEFAULT = F_SKYBOX | F_ANTIALIAS | F_DEFOCUS | F_BVH
+READ_RAW_SUM, READ_AVERAGE, READ_TONEMAPPED = 0, 1, 2
+(OP_TRI_INTERSECT, OP_AABB_DIST, OP_SPHERE, OP_FLOOR, OP_ITRI_PDF, OP_ITRI_SAMPLE, OP_ATTRACTOR_PDF,
+ OP_ATTRACTOR_SAMPLE, OP_TONEMAP, OP_RNG, OP_ENV_INDEX, OP_CAMERA_RAY) = range(1, 13)
+OP_STRIDES = {OP_TRI_INTERSECT: (15, 4), OP_AABB_DIST: (12, 1), OP_SPHERE: (10, 7), OP_FLOOR: (7, 7),
+              OP_ITRI_PDF: (15, 1), OP_ITRI_SAMPLE: (14, 3), OP_ATTRACTOR_PDF: (15, 1),
+              OP_ATTRACTOR_SAMPLE: (14, 3), OP_TONEMAP: (3, 3), OP_RNG: (4, 4), OP_ENV_INDEX: (5, 1),
+              OP_CAMERA_RAY: (3, 6)}
+TRI_FLOATS = 25
+
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback",
+              "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
+              "rt_trace_rays", "rt_debug_op", "rt_shade_hits"]
+SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
+                 "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
+                 "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
+                 "rt_host_free"]
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def _load(name: str) -> C.CDLL:
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `make` (or __graft_entry__.build()) first; "
+                           "there is no fallback path")
+    return C.CDLL(path)
+
+
+_scene_lib: Optional[C.CDLL] = None
+_core_lib: Optional[C.CDLL] = None
+
+
+def scene_lib() -> C.CDLL:
+    global _scene_lib
+    if _scene_lib is None:
+        L = _load("librt_scene.so")
+        L.rt_scene_last_error.restype = C.c_char_p
+        L.rt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_void_p)]
+        L.rt_scene_from_records.argtypes = [_fp, C.c_size_t, C.POINTER(Material), C.c_size_t, _fp, C.c_size_t,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_synth_field.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
+                                           C.c_int, C.POINTER(C.c_void_p)]
+        L.rt_scene_free.argtypes = [C.c_void_p]
+        L.rt_scene_free.restype = None
+        L.rt_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.rt_scene_get_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
+        L.rt_scene_bvh_depth.argtypes = [C.c_void_p]
+        L.rt_bvh_build.argtypes = [_fp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(BvhNode)), _ip]
+        L.rt_obj_load.argtypes = [C.c_char_p, _fp, C.c_float, _fp, C.c_int, C.POINTER(_fp),
+                                  C.POINTER(C.c_size_t)]
+        L.rt_noise_texture.argtypes = [C.c_int, C.c_int, _fp]
+        L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(_fp), _ip, _ip]
+        L.rt_image_save.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int]
+        L.rt_host_free.argtypes = [C.c_void_p]
+        L.rt_host_free.restype = None
+        _scene_lib = L
+    return _scene_lib
+
+
+def core_lib() -> C.CDLL:
+    global _core_lib
+    if _core_lib is None:
+        L = _load("librt_amd.so")
+        L.rt_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.rt_destroy.argtypes = [C.c_void_p]
+        L.rt_destroy.restype = None
+        L.rt_last_error.argtypes = [C.c_void_p]
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(RenderStats)]
+        L.rt_readback.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_int]
+        L.rt_reset_accum.argtypes = [C.c_void_p]
+        L.rt_bind_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rt_set_sample_count.argtypes = [C.c_void_p, C.c_int64]
+        L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.rt_trace_rays.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _ip, _fp, _fp, _fp, _ip]
+        L.rt_debug_op.argtypes = [C.c_void_p, C.c_int, _fp, C.c_size_t, _fp, C.POINTER(RenderParams)]
+        L.rt_shade_hits.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _fp]
+        _core_lib = L
+    return _core_lib
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray, typ=_fp):
+    return a.ctypes.data_as(typ)
+
+
+# ----------------------------------------------------------------------------- host scene
+
+
+class Scene:
+    """Host scene = the arrays of render2's argument list (rt_scene_desc)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+        self.desc = SceneDesc()
+        self.camera = Camera()
+        L = scene_lib()
+        if L.rt_scene_get_desc(self._h, C.byref(self.desc)) or L.rt_scene_get_camera(self._h, C.byref(self.camera)):
+            raise RuntimeError(L.rt_scene_last_error().decode())
+
+    @staticmethod
+    def _check(rc: int, out: C.c_void_p) -> "Scene":
+        if rc != 0:
+            raise RuntimeError("scene: " + scene_lib().rt_scene_last_error().decode())
+        return Scene(out.value)
+
+    @classmethod
+    def load(cls, scene_path: str, asset_root: Optional[str] = ASSET_DIR, env_override: Optional[str] = None,
+             enable_spheres: bool = False, bvh_max_depth: int = 16, bvh_min_tris: int = 4) -> "Scene":
+        if not os.path.isabs(scene_path) and not os.path.exists(scene_path):
+            scene_path = os.path.join(SCENE_DIR, scene_path)
+        out = C.c_void_p()
+        rc = scene_lib().rt_scene_load(scene_path.encode(), asset_root.encode() if asset_root else None,
+                                       env_override.encode() if env_override else None, int(enable_spheres),
+                                       bvh_max_depth, bvh_min_tris, C.byref(out))
+        return cls._check(rc, out)
+
+    @classmethod
+    def from_records(cls, tris, mats, textures=None, env_w=0, env_h=0, bvh_max_depth=16, bvh_min_tris=4):
+        tris = _f32(tris).ravel()
+        marr = (Material * len(mats))(*mats)
+        tex = _f32(textures).ravel() if textures is not None else None
+        out = C.c_void_p()
+        rc = scene_lib().rt_scene_from_records(_ptr(tris), tris.size, marr, len(mats),
+                                               _ptr(tex) if tex is not None else None,
+                                               tex.size if tex is not None else 0, env_w, env_h,
+                                               bvh_max_depth, bvh_min_tris, C.byref(out))
+        return cls._check(rc, out)
+
+    @classmethod
+    def synth_field(cls, instances: int, seed: int = 1234, obj_path: Optional[str] = None,
+                    env_path: Optional[str] = None, env_upsample: int = 1, bvh_max_depth=16, bvh_min_tris=4):
+        obj_path = obj_path or os.path.join(ASSET_DIR, "dragon.obj")
+        out = C.c_void_p()
+        rc = scene_lib().rt_scene_synth_field(obj_path.encode(), instances, seed,
+                                              env_path.encode() if env_path else None, env_upsample,
+                                              bvh_max_depth, bvh_min_tris, C.byref(out))
+        return cls._check(rc, out)
+
+    def close(self):
+        if self._h:
+            scene_lib().rt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy views (valid while the scene lives)
+    @property
+    def n_tris(self) -> int:
+        return self.desc.n_tri_floats // TRI_FLOATS
+
+    @property
+    def prefix(self) -> int:
+        return 1 + 5 * self.desc.n_spheres if self.desc.n_spheres > 0 else 0
+
+    def tris(self) -> np.ndarray:
+        n = self.desc.n_tri_floats
+        a = np.ctypeslib.as_array(self.desc.tris, shape=(self.prefix + n,))
+        return a[self.prefix:].reshape(-1, TRI_FLOATS)
+
+    def nodes(self) -> np.ndarray:
+        dt = np.dtype([("bbox_min", "<f4", 3), ("bbox_max", "<f4", 3), ("child_a", "<i4"), ("child_b", "<i4"),
+                       ("tri_offs", "<i4"), ("tri_len", "<i4")])
+        n = self.desc.n_nodes
+        buf = C.cast(self.desc.nodes, C.POINTER(C.c_char * (40 * n))).contents
+        return np.frombuffer(buf, dtype=dt, count=n)
+
+    def materials(self):
+        return [self.desc.mats[i] for i in range(self.desc.n_mats)]
+
+    def textures(self) -> np.ndarray:
+        n = self.desc.n_tex_floats
+        if n == 0:
+            return np.zeros(0, np.float32)
+        return np.ctypeslib.as_array(self.desc.textures, shape=(n,))
+
+    def lights(self) -> np.ndarray:
+        n = self.desc.n_light_tris
+        if n == 0:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(self.desc.light_tris, shape=(n,))
+
+    def bvh_depth(self) -> int:
+        return scene_lib().rt_scene_bvh_depth(self._h)
+
+
+def default_params(cam: Camera, spp: Optional[int] = None, max_bounces: int = 6, seed: int = 37811,
+                   flags: int = F_DEFAULT, width: Optional[int] = None, height: Optional[int] = None) -> RenderParams:
+    """Reference defaults: MAX_BOUNCES 6 (config.h:3), seed 37811 (main.cu:171), background
+    (1,1,0.05)*0.5 (config.h:6-7)."""
+    p = RenderParams()
+    C.memmove(C.byref(p.cam), C.byref(cam), C.sizeof(Camera))
+    if width:
+        p.cam.width = width
+    if height:
+        p.cam.height = height
+    p.max_bounces = max_bounces
+    p.flags = flags
+    p.seed = seed
+    p.sample_begin = 0
+    p.sample_count = spp if spp is not None else cam.num_samples
+    p.band_rows, p.band_stride, p.band_index = 0, 1, 0
+    p.background[:] = [1.0, 1.0, 0.05]
+    p.background_brightness = 0.5
+    return p
+
+
+def band_rows_of(params: RenderParams) -> int:
+    """Number of accumulator rows a call with these params renders (rt.h: tile-row partition)."""
+    H = params.cam.height
+    if params.band_stride <= 1 or params.band_rows <= 0:
+        return H
+    rows = 0
+    for y0 in range(0, H, params.band_rows):
+        if (y0 // params.band_rows) % params.band_stride == params.band_index:
+            rows += min(params.band_rows, H - y0)
+    return rows
+
+
+# ----------------------------------------------------------------------------- device context
+
+
+class Renderer:
+    """One rt_context (one HIP device).  Mirrors the render call of main(): upload, launch, readback."""
+
+    def __init__(self, device_id: int = -1):
+        self._L = core_lib()
+        self._h = C.c_void_p()
+        rc = self._L.rt_create(C.byref(self._h), device_id)
+        if rc != 0:
+            raise RuntimeError(f"rt_create failed ({rc}): no usable HIP device; there is no CPU fallback")
+        self._rows = 0
+        self._width = 0
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"rt error {rc}: {self._L.rt_last_error(self._h).decode()}")
+
+    def close(self):
+        if self._h:
+            self._L.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene: Scene):
+        self._ck(self._L.rt_upload_scene(self._h, C.byref(scene.desc)))
+
+    def render(self, params: RenderParams, want_stats: bool = True) -> Optional[RenderStats]:
+        st = RenderStats()
+        self._ck(self._L.rt_render(self._h, C.byref(params), C.byref(st)))
+        self._rows = band_rows_of(params)
+        self._width = params.cam.width
+        return st if want_stats else None
+
+    def readback(self, mode: int = READ_RAW_SUM) -> np.ndarray:
+        out = np.empty((self._rows, self._width, 3), np.float32)
+        self._ck(self._L.rt_readback(self._h, _ptr(out), out.size, mode))
+        return out
+
+    def reset(self):
+        self._ck(self._L.rt_reset_accum(self._h))
+
+    def bind_accum(self, dev_ptr: int, n_floats: int):
+        self._ck(self._L.rt_bind_accum(self._h, C.c_void_p(dev_ptr), n_floats))
+
+    def set_sample_count(self, n: int):
+        self._ck(self._L.rt_set_sample_count(self._h, n))
+
+    def set_stream(self, stream_ptr: int):
+        self._ck(self._L.rt_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def resolve_device(self, dev_ptr: int, n_floats: int, mode: int):
+        self._ck(self._L.rt_resolve_device(self._h, C.c_void_p(dev_ptr), n_floats, mode))
+
+    def trace_rays(self, org_dir, flags: int = F_BVH, want_counts: bool = False):
+        rays = _f32(org_dir).reshape(-1, 6)
+        n = rays.shape[0]
+        prim = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        pos = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        cnt = np.empty((n, 3), np.int32) if want_counts else None
+        self._ck(self._L.rt_trace_rays(self._h, _ptr(rays), n, flags, _ptr(prim, _ip), _ptr(t), _ptr(pos),
+                                       _ptr(nrm), _ptr(cnt, _ip) if want_counts else None))
+        return prim, t, pos, nrm, cnt
+
+    def debug_op(self, op: int, records, params: Optional[RenderParams] = None) -> np.ndarray:
+        si, so = OP_STRIDES[op]
+        a = np.ascontiguousarray(records).view(np.float32).reshape(-1, si)
+        out = np.zeros((a.shape[0], so), np.float32)
+        self._ck(self._L.rt_debug_op(self._h, op, _ptr(a), a.shape[0], _ptr(out),
+                                     C.byref(params) if params is not None else None))
+        return out
+
+    def shade_hits(self, records, seed: int) -> np.ndarray:
+        a = np.ascontiguousarray(records).view(np.float32).reshape(-1, 16)
+        out = np.zeros_like(a)
+        self._ck(self._L.rt_shade_hits(self._h, _ptr(a), a.shape[0], seed, _ptr(out)))
+        return out

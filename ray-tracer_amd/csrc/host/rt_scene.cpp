@@ -1,0 +1,1121 @@
+// rt_scene.cpp -- host-side scene assembly (see include/rt_scene.h).
+//
+// Own implementation of the reference's host producers; behaviour follows
+//   src/sceneParser.cpp, src/model.h, src/BVHcreator.cpp, src/noiseTexture.cpp,
+//   src/texture.cpp (citations at each function).
+// Plain C++17, no GPU, no third-party code.  Build with -ffp-contract=off so
+// the float op order below is what is executed.
+
+#include "rt_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+    g_err = msg;
+    return RT_ERR_INVALID;
+}
+
+struct V3 {
+    float x = 0.f, y = 0.f, z = 0.f;
+};
+
+// Matrix::rotationMatrix, matrix.h:14-37 (XYZ Euler).  Float sin/cos.
+struct Mat3 {
+    float m[9];
+};
+
+Mat3 rotation_matrix(const V3& v) {
+    Mat3 r;
+    const float cx = cosf(v.x), sx = sinf(v.x);
+    const float cy = cosf(v.y), sy = sinf(v.y);
+    const float cz = cosf(v.z), sz = sinf(v.z);
+    r.m[0] = cy * cz;
+    r.m[1] = -cy * sz;
+    r.m[2] = sy;
+    r.m[3] = cx * sz + sx * sy * cz;
+    r.m[4] = cx * cz - sx * sy * sz;
+    r.m[5] = -sx * cy;
+    r.m[6] = sx * sz - cx * sy * cz;
+    r.m[7] = sx * cz + cx * sy * sz;
+    r.m[8] = cx * cy;
+    return r;
+}
+
+// operator*(Matrix, Vec3), matrix.h:48-54: left-to-right sums.
+V3 mul(const Mat3& a, const V3& v) {
+    V3 r;
+    r.x = a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z;
+    r.y = a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z;
+    r.z = a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z;
+    return r;
+}
+
+// ------------------------------------------------------------------ images
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<float> rgb;
+};
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; i++)
+        if (tolower((unsigned char)s[s.size() - n + i]) != suf[i]) return false;
+    return true;
+}
+
+bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), f);
+    fclose(f);
+    return got == out.size();
+}
+
+// Radiance RGBE -> float as stb_image does it (value = mantissa * 2^(e-136),
+// no half-step offset; e == 0 -> black).
+inline void rgbe_to_float(const unsigned char* p, float* out) {
+    if (p[3] != 0) {
+        const float f1 = (float)ldexp(1.0f, (int)p[3] - (128 + 8));
+        out[0] = p[0] * f1;
+        out[1] = p[1] * f1;
+        out[2] = p[2] * f1;
+    } else {
+        out[0] = out[1] = out[2] = 0.f;
+    }
+}
+
+bool load_hdr(const std::string& path, Image& img, std::string& err) {
+    std::vector<unsigned char> buf;
+    if (!read_file(path, buf)) {
+        err = "could not open image: " + path;
+        return false;
+    }
+    size_t pos = 0;
+    auto next_line = [&](std::string& line) {
+        line.clear();
+        while (pos < buf.size() && buf[pos] != '\n') line.push_back((char)buf[pos++]);
+        if (pos < buf.size()) pos++;
+    };
+    std::string line;
+    next_line(line);
+    if (line != "#?RADIANCE" && line != "#?RGBE") {
+        err = "not a Radiance HDR file: " + path;
+        return false;
+    }
+    bool fmt_ok = false;
+    for (;;) {
+        next_line(line);
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") fmt_ok = true;
+        if (pos >= buf.size()) break;
+    }
+    if (!fmt_ok) {
+        err = "unsupported HDR format: " + path;
+        return false;
+    }
+    next_line(line);
+    int h = 0, w = 0;
+    if (sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) {
+        err = "unsupported HDR orientation: " + path;
+        return false;
+    }
+    img.w = w;
+    img.h = h;
+    img.rgb.assign((size_t)w * h * 3, 0.f);
+    std::vector<unsigned char> scan((size_t)w * 4);
+    auto need = [&](size_t n) { return pos + n <= buf.size(); };
+    if (w < 8 || w >= 32768) {  // flat
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            if (!need(4)) { err = "truncated HDR: " + path; return false; }
+            rgbe_to_float(&buf[pos], &img.rgb[i * 3]);
+            pos += 4;
+        }
+        return true;
+    }
+    for (int y = 0; y < h; y++) {
+        if (!need(4)) { err = "truncated HDR: " + path; return false; }
+        const unsigned char c1 = buf[pos], c2 = buf[pos + 1], len = buf[pos + 2];
+        if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+            // not run-length encoded: whole file is flat from here (first scanline only case)
+            if (y != 0) { err = "mixed HDR encodings: " + path; return false; }
+            for (size_t i = 0; i < (size_t)w * h; i++) {
+                if (!need(4)) { err = "truncated HDR: " + path; return false; }
+                rgbe_to_float(&buf[pos], &img.rgb[i * 3]);
+                pos += 4;
+            }
+            return true;
+        }
+        const int sl = ((int)len << 8) | buf[pos + 3];
+        pos += 4;
+        if (sl != w) { err = "corrupt HDR scanline width: " + path; return false; }
+        for (int k = 0; k < 4; k++) {
+            int i = 0;
+            while (i < w) {
+                if (!need(1)) { err = "truncated HDR: " + path; return false; }
+                unsigned char count = buf[pos++];
+                if (count > 128) {  // run
+                    count -= 128;
+                    if (!need(1) || count == 0 || i + count > w) { err = "corrupt HDR run: " + path; return false; }
+                    const unsigned char v = buf[pos++];
+                    for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + k] = v;
+                } else {  // dump
+                    if (count == 0 || !need(count) || i + count > w) { err = "corrupt HDR dump: " + path; return false; }
+                    for (int z = 0; z < count; z++) scan[(size_t)(i++) * 4 + k] = buf[pos++];
+                }
+            }
+        }
+        for (int x = 0; x < w; x++) rgbe_to_float(&scan[(size_t)x * 4], &img.rgb[((size_t)y * w + x) * 3]);
+    }
+    return true;
+}
+
+bool ppm_token(const std::vector<unsigned char>& buf, size_t& pos, std::string& tok) {
+    tok.clear();
+    for (;;) {
+        while (pos < buf.size() && isspace(buf[pos])) pos++;
+        if (pos < buf.size() && buf[pos] == '#') {
+            while (pos < buf.size() && buf[pos] != '\n') pos++;
+            continue;
+        }
+        break;
+    }
+    while (pos < buf.size() && !isspace(buf[pos])) tok.push_back((char)buf[pos++]);
+    return !tok.empty();
+}
+
+bool load_ppm(const std::string& path, Image& img, std::string& err) {
+    std::vector<unsigned char> buf;
+    if (!read_file(path, buf)) { err = "could not open image: " + path; return false; }
+    size_t pos = 0;
+    std::string t;
+    if (!ppm_token(buf, pos, t) || t != "P6") { err = "not a binary PPM: " + path; return false; }
+    int w = 0, h = 0, mx = 0;
+    if (!ppm_token(buf, pos, t)) { err = "bad PPM header"; return false; }
+    w = atoi(t.c_str());
+    if (!ppm_token(buf, pos, t)) { err = "bad PPM header"; return false; }
+    h = atoi(t.c_str());
+    if (!ppm_token(buf, pos, t)) { err = "bad PPM header"; return false; }
+    mx = atoi(t.c_str());
+    pos++;  // single whitespace after maxval
+    if (w <= 0 || h <= 0 || mx != 255 || pos + (size_t)w * h * 3 > buf.size()) {
+        err = "unsupported or truncated PPM: " + path;
+        return false;
+    }
+    img.w = w;
+    img.h = h;
+    img.rgb.resize((size_t)w * h * 3);
+    // stbi_loadf on LDR input: pow(v/255, 2.2) evaluated in double (stb's ldr_to_hdr).
+    float lut[256];
+    for (int i = 0; i < 256; i++) lut[i] = (float)(pow((double)(i / 255.0f), (double)2.2f) * (double)1.0f);
+    for (size_t i = 0; i < img.rgb.size(); i++) img.rgb[i] = lut[buf[pos + i]];
+    return true;
+}
+
+bool load_pfm(const std::string& path, Image& img, std::string& err) {
+    std::vector<unsigned char> buf;
+    if (!read_file(path, buf)) { err = "could not open image: " + path; return false; }
+    size_t pos = 0;
+    std::string t;
+    if (!ppm_token(buf, pos, t) || t != "PF") { err = "not a colour PFM: " + path; return false; }
+    if (!ppm_token(buf, pos, t)) { err = "bad PFM header"; return false; }
+    const int w = atoi(t.c_str());
+    if (!ppm_token(buf, pos, t)) { err = "bad PFM header"; return false; }
+    const int h = atoi(t.c_str());
+    if (!ppm_token(buf, pos, t)) { err = "bad PFM header"; return false; }
+    const double scale = atof(t.c_str());
+    pos++;
+    if (w <= 0 || h <= 0 || scale >= 0 || pos + (size_t)w * h * 12 > buf.size()) {
+        err = "unsupported (big-endian?) or truncated PFM: " + path;
+        return false;
+    }
+    img.w = w;
+    img.h = h;
+    img.rgb.resize((size_t)w * h * 3);
+    // PFM rows are bottom-to-top
+    for (int y = 0; y < h; y++)
+        memcpy(&img.rgb[(size_t)y * w * 3], &buf[pos + (size_t)(h - 1 - y) * w * 12], (size_t)w * 12);
+    return true;
+}
+
+bool load_image(const std::string& path, Image& img, std::string& err) {
+    if (ends_with(path, ".hdr")) return load_hdr(path, img, err);
+    if (ends_with(path, ".ppm")) return load_ppm(path, img, err);
+    if (ends_with(path, ".pfm")) return load_pfm(path, img, err);
+    err = "unsupported image format (need .hdr/.ppm/.pfm): " + path;
+    return false;
+}
+
+// ------------------------------------------------------------------ noise
+
+// NoiseTexture::fourier_series, noiseTexture.cpp:13-20
+float fourier_series(float x, float y) {
+    float h = 0.0f;
+    h += sinf(x * 1.52f + y * 23.0f);
+    h += sinf(x * 9.5f + y * 10.0f) * 0.9f;
+    h += sinf(x * 15.5f + y * 23.0f) * 0.7f;
+    h += sinf(x * 35.0f + y * 2.0f) * 0.5f;
+    return h;
+}
+
+// NoiseTexture::generate, noiseTexture.cpp:22-40.  Double literals in the
+// reference promote those products to double; kept.
+void noise_generate(int width, int height, float* data) {
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            const float u = static_cast<float>(x) / width;
+            const float v = static_cast<float>(y) / height;
+            float ux = u, uy = v;
+            ux = (float)((double)ux + (double)fourier_series(ux + 0.2f, uy + 0.9f) * 0.1);
+            uy = (float)((double)uy + (double)fourier_series(ux + 0.1f, uy + 0.3f) * 0.1);
+            float h = fourier_series(ux, uy);
+            h = (float)(1.0 / (1.0 + std::exp((double)(-h) * 2.0)));
+            const size_t idx = ((size_t)y * width + x) * 3;
+            data[idx] = h;
+            data[idx + 1] = h;
+            data[idx + 2] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ OBJ
+
+struct ParsedObj {
+    std::vector<float> v, vn, vt;  // raw (untransformed)
+    std::vector<int> idx;          // 9 per face: v0 v1 v2 n0 n1 n2 t0 t1 t2 (1-based, 0 = absent)
+};
+
+bool parse_obj(const std::string& path, ParsedObj& o, std::string& err) {
+    std::ifstream file(path);
+    if (!file.is_open()) {
+        err = "could not open model file: " + path;
+        return false;
+    }
+    std::string line;
+    while (std::getline(file, line)) {
+        if (line.size() < 2) continue;
+        const char c0 = line[0], c1 = line[1];
+        if (c0 == 'v' && c1 == ' ') {
+            float x = 0, y = 0, z = 0;
+            sscanf(line.c_str(), "v %f %f %f", &x, &y, &z);
+            o.v.push_back(x); o.v.push_back(y); o.v.push_back(z);
+        } else if (c0 == 'v' && c1 == 'n') {
+            float x = 0, y = 0, z = 0;
+            sscanf(line.c_str(), "vn %f %f %f", &x, &y, &z);
+            o.vn.push_back(x); o.vn.push_back(y); o.vn.push_back(z);
+        } else if (c0 == 'v' && c1 == 't') {
+            float u = 0, v = 0;
+            sscanf(line.c_str(), "vt %f %f", &u, &v);
+            o.vt.push_back(u); o.vt.push_back(v);
+        } else if (c0 == 'f' && c1 == ' ') {
+            int v[3] = {0, 0, 0}, t[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+            const char* s = line.c_str();
+            if (sscanf(s, "f %d/%d/%d %d/%d/%d %d/%d/%d", &v[0], &t[0], &n[0], &v[1], &t[1], &n[1], &v[2], &t[2], &n[2]) == 9) {
+            } else if (sscanf(s, "f %d//%d %d//%d %d//%d", &v[0], &n[0], &v[1], &n[1], &v[2], &n[2]) == 6) {
+                t[0] = t[1] = t[2] = 0;
+            } else if (sscanf(s, "f %d/%d %d/%d %d/%d", &v[0], &t[0], &v[1], &t[1], &v[2], &t[2]) == 6) {
+                n[0] = n[1] = n[2] = 0;
+            } else if (sscanf(s, "f %d %d %d", &v[0], &v[1], &v[2]) == 3) {
+                t[0] = t[1] = t[2] = 0;
+                n[0] = n[1] = n[2] = 0;
+            } else {
+                err = "unsupported face line in " + path + ": " + line;
+                return false;
+            }
+            const int nv = (int)(o.v.size() / 3), nn = (int)(o.vn.size() / 3), nt = (int)(o.vt.size() / 2);
+            for (int k = 0; k < 3; k++) {
+                if (v[k] < 1 || v[k] > nv || n[k] < 0 || n[k] > nn || t[k] < 0 || t[k] > nt) {
+                    err = "face index out of range in " + path + ": " + line;
+                    return false;
+                }
+            }
+            for (int k = 0; k < 3; k++) o.idx.push_back(v[k]);
+            for (int k = 0; k < 3; k++) o.idx.push_back(n[k]);
+            for (int k = 0; k < 3; k++) o.idx.push_back(t[k]);
+        }
+    }
+    return true;
+}
+
+// Model::loadMesh, model.h:62-163: v' = (R*v)*scale + T ; n' = R*n ; records in face order.
+void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index,
+                  std::vector<float>& out) {
+    const Mat3 R = rotation_matrix(rot);
+    std::vector<float> verts(o.v.size()), norms(o.vn.size());
+    for (size_t i = 0; i < o.v.size(); i += 3) {
+        V3 p{o.v[i], o.v[i + 1], o.v[i + 2]};
+        V3 r = mul(R, p);
+        verts[i] = r.x * scale + T.x;
+        verts[i + 1] = r.y * scale + T.y;
+        verts[i + 2] = r.z * scale + T.z;
+    }
+    for (size_t i = 0; i < o.vn.size(); i += 3) {
+        V3 p{o.vn[i], o.vn[i + 1], o.vn[i + 2]};
+        V3 r = mul(R, p);
+        norms[i] = r.x; norms[i + 1] = r.y; norms[i + 2] = r.z;
+    }
+    const float matf = (float)((double)static_cast<float>(material_index) + 0.001);  // model.h:162
+    const size_t base = out.size();
+    out.resize(base + o.idx.size() / 9 * RT_TRI_FLOATS);
+    float* w = out.data() + base;
+    for (size_t i = 0; i < o.idx.size(); i += 9, w += RT_TRI_FLOATS) {
+        for (int k = 0; k < 3; k++) {
+            const int vi = (o.idx[i + k] - 1) * 3;
+            w[k * 3 + 0] = verts[vi]; w[k * 3 + 1] = verts[vi + 1]; w[k * 3 + 2] = verts[vi + 2];
+        }
+        bool have_n = o.idx[i + 3] > 0 && o.idx[i + 4] > 0 && o.idx[i + 5] > 0;
+        if (have_n) {
+            for (int k = 0; k < 3; k++) {
+                const int ni = (o.idx[i + 3 + k] - 1) * 3;
+                w[9 + k * 3 + 0] = norms[ni]; w[9 + k * 3 + 1] = norms[ni + 1]; w[9 + k * 3 + 2] = norms[ni + 2];
+            }
+        } else {  // extension: geometric normal when the file has none
+            const float e1x = w[3] - w[0], e1y = w[4] - w[1], e1z = w[5] - w[2];
+            const float e2x = w[6] - w[0], e2y = w[7] - w[1], e2z = w[8] - w[2];
+            float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+            const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+            if (len > 0) { nx /= len; ny /= len; nz /= len; }
+            for (int k = 0; k < 3; k++) { w[9 + k * 3] = nx; w[10 + k * 3] = ny; w[11 + k * 3] = nz; }
+        }
+        for (int k = 0; k < 3; k++) {
+            const int ti = o.idx[i + 6 + k];
+            w[18 + k * 2] = ti > 0 ? o.vt[(ti - 1) * 2] : 0.f;
+            w[19 + k * 2] = ti > 0 ? o.vt[(ti - 1) * 2 + 1] : 0.f;
+        }
+        w[24] = matf;
+    }
+}
+
+// ------------------------------------------------------------------ BVH
+
+struct TmpNode {
+    float mn[3], mx[3];
+    std::vector<uint32_t> tris;  // triangle indices (records), input order preserved
+    int a = -1, b = -1;
+    int depth = 0;
+    int index = -1;
+};
+
+inline void grow_box(float* mn, float* mx, const float* tri) {
+    for (int v = 0; v < 3; v++) {
+        mn[0] = fminf(mn[0], tri[v * 3 + 0]);
+        mn[1] = fminf(mn[1], tri[v * 3 + 1]);
+        mn[2] = fminf(mn[2], tri[v * 3 + 2]);
+        mx[0] = fmaxf(mx[0], tri[v * 3 + 0]);
+        mx[1] = fmaxf(mx[1], tri[v * 3 + 1]);
+        mx[2] = fmaxf(mx[2], tri[v * 3 + 2]);
+    }
+}
+
+// splitNode, BVHcreator.cpp:86-170.  Returns false if the node stays a leaf.
+bool split_node(std::vector<TmpNode>& nodes, int ni, const float* tris) {
+    {
+        TmpNode& n = nodes[ni];
+        if (n.tris.size() <= 2) return false;  // :97-99
+    }
+    const int ia = (int)nodes.size();
+    nodes.emplace_back();
+    nodes.emplace_back();
+    TmpNode& n = nodes[ni];
+    TmpNode& A = nodes[ia];
+    TmpNode& B = nodes[ia + 1];
+    n.a = ia;
+    n.b = ia + 1;
+    A.depth = B.depth = n.depth + 1;
+    const float xw = n.mx[0] - n.mn[0], yw = n.mx[1] - n.mn[1], zw = n.mx[2] - n.mn[2];
+    int axis;
+    if (xw >= yw && xw >= zw) axis = 0;
+    else if (yw >= xw && yw >= zw) axis = 1;
+    else axis = 2;
+    float mean = 0.0f;  // float accumulation in triangle order, :113-123
+    for (uint32_t t : n.tris) {
+        const float* tri = tris + (size_t)t * RT_TRI_FLOATS;
+        mean += (tri[axis] + tri[3 + axis] + tri[6 + axis]);
+    }
+    mean /= static_cast<float>(n.tris.size() * 3);
+    for (uint32_t t : n.tris) {
+        const float* tri = tris + (size_t)t * RT_TRI_FLOATS;
+        const float c = (tri[axis] + tri[3 + axis] + tri[6 + axis]) / 3.0f;
+        if (c < mean) A.tris.push_back(t);
+        else B.tris.push_back(t);
+    }
+    for (TmpNode* c : {&A, &B}) {
+        c->mn[0] = c->mn[1] = c->mn[2] = 1e12f;
+        c->mx[0] = c->mx[1] = c->mx[2] = -1e12f;
+        for (uint32_t t : c->tris) grow_box(c->mn, c->mx, tris + (size_t)t * RT_TRI_FLOATS);
+    }
+    n.tris.clear();
+    n.tris.shrink_to_fit();
+    return true;
+}
+
+// createBVH, BVHcreator.cpp:240-256 (+ createInitialNode :187-205, splitRecursive
+// :173-184, BFSIndex :41-61, populateBVHNodes :209-237).
+int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::vector<rt_bvh_node>& out,
+              int* out_depth) {
+    if (n_floats % RT_TRI_FLOATS != 0) return fail("triangle array length is not a multiple of 25");
+    const size_t ntri = n_floats / RT_TRI_FLOATS;
+    if (ntri > 0x7fffffffu / RT_TRI_FLOATS) return fail("too many triangles for int32 float offsets");
+    std::vector<TmpNode> nodes;
+    nodes.reserve(1024);
+    nodes.emplace_back();
+    {
+        TmpNode& r = nodes[0];
+        r.depth = 0;
+        r.mn[0] = r.mn[1] = r.mn[2] = 1e12f;
+        r.mx[0] = r.mx[1] = r.mx[2] = -1e12f;
+        r.tris.resize(ntri);
+        for (size_t i = 0; i < ntri; i++) {
+            grow_box(r.mn, r.mx, tris + i * RT_TRI_FLOATS);
+            r.tris[i] = (uint32_t)i;
+        }
+    }
+    // depth-first A-then-B like splitRecursive (order of creation does not
+    // matter for the result; numbering is assigned by the BFS below).
+    std::vector<int> todo{0};
+    while (!todo.empty()) {
+        const int ni = todo.back();
+        todo.pop_back();
+        if (nodes[ni].depth >= max_depth || (int)nodes[ni].tris.size() <= min_tris) continue;
+        if (!split_node(nodes, ni, tris)) continue;
+        todo.push_back(nodes[ni].b);
+        todo.push_back(nodes[ni].a);
+    }
+    // BFS numbering, A before B.
+    std::vector<int> order;
+    order.reserve(nodes.size());
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        TmpNode& n = nodes[order[head]];
+        n.index = (int)head;
+        if (n.a >= 0) order.push_back(n.a);
+        if (n.b >= 0) order.push_back(n.b);
+    }
+    out.resize(order.size());
+    std::vector<float> newtris(n_floats);
+    int offs = 0, depth = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+        const TmpNode& n = nodes[order[k]];
+        rt_bvh_node& o = out[k];
+        for (int c = 0; c < 3; c++) { o.bbox_min[c] = n.mn[c]; o.bbox_max[c] = n.mx[c]; }
+        o.child_a = n.a >= 0 ? nodes[n.a].index : -1;
+        o.child_b = n.b >= 0 ? nodes[n.b].index : -1;
+        o.tri_offs = offs;
+        o.tri_len = (int)n.tris.size() * RT_TRI_FLOATS;
+        for (uint32_t t : n.tris) {
+            memcpy(&newtris[offs], tris + (size_t)t * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
+            offs += RT_TRI_FLOATS;
+        }
+        if (n.a < 0) depth = std::max(depth, n.depth);
+    }
+    if (n_floats) memcpy(tris, newtris.data(), n_floats * sizeof(float));
+    if (out_depth) *out_depth = depth;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ scene DSL
+
+// SceneParser::nth_word, sceneParser.cpp:307-326 (split on single spaces).
+std::string nth_word(const std::string& line, int n) {
+    size_t start = 0;
+    size_t end = line.find(' ');
+    int count = 0;
+    while (end != std::string::npos) {
+        if (count == n) return line.substr(start, end - start);
+        start = end + 1;
+        end = line.find(' ', start);
+        count++;
+    }
+    if (count == n) return line.substr(start);
+    return "";
+}
+
+struct ATexture { std::string name, path; bool loaded = false; int offset = 0, w = 0, h = 0; };
+struct AModel { std::string name, path; };
+// Members the reference leaves uninitialised (sceneParser.h:25-33, 39-46)
+// default to 0 / scale 1 here.
+struct AMaterial { std::string name; int type = 0; V3 color; float p1 = 0, p2 = 0, p3 = 0; std::vector<std::string> images; };
+struct AObject { std::string name, model, material; };
+struct AInstance { std::string object; V3 pos, rot; float scale = 1.0f; bool importance = false; };
+struct ASphere { V3 pos; float radius = 0.f; std::string material; };
+
+}  // namespace
+
+struct rt_host_scene {
+    rt_camera cam{};
+    std::vector<float> tris;  // sphere prefix + records
+    int n_spheres = 0;
+    std::vector<rt_bvh_node> nodes;
+    std::vector<rt_material> mats;
+    std::vector<float> textures;
+    std::vector<int32_t> lights;
+    int bvh_depth = 0;
+};
+
+namespace {
+
+bool stof_ok(const std::string& s, float& out) {
+    try {
+        out = std::stof(s);
+        return true;
+    } catch (...) {
+        return false;
+    }
+}
+bool stoi_ok(const std::string& s, int& out) {
+    try {
+        out = std::stoi(s);
+        return true;
+    } catch (...) {
+        return false;
+    }
+}
+
+struct Parser {
+    rt_camera cam{};
+    std::vector<ATexture> textures;
+    std::vector<AModel> models;
+    std::vector<AMaterial> materials;
+    std::vector<AObject> objects;
+    std::vector<AInstance> instances;
+    std::vector<ASphere> spheres;
+    std::string background;
+    std::string err;
+    bool enable_spheres = false;
+
+    Parser() {
+        // SceneConfigs defaults, sceneConfigs.h:6-17
+        cam.width = 512; cam.height = 512; cam.num_samples = 1000;
+        cam.focal_length = 1.0f; cam.aperture = 0.0f; cam.focus_distance = 4.0f;
+        cam.env_width = 0; cam.env_height = 0;  // (reference: 4096x2048 even without an env map; forced to 0 = none)
+    }
+
+    bool vec3(const std::string& line, V3& v) {
+        return stof_ok(nth_word(line, 1), v.x) && stof_ok(nth_word(line, 2), v.y) && stof_ok(nth_word(line, 3), v.z);
+    }
+    bool vec3(const std::string& line, float* v) {
+        V3 t;
+        if (!vec3(line, t)) return false;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z;
+        return true;
+    }
+
+    // sceneParser.cpp:22-171
+    bool parse(const std::string& path) {
+        std::ifstream file(path);
+        if (!file.is_open()) { err = "could not open scene file: " + path; return false; }
+        enum Scope { GLOBAL, IMAGE, MODEL, MATERIAL, OBJECT, INSTANCE, SPHERE } scope = GLOBAL;
+        std::string line;
+        int lineno = 0;
+        auto bad = [&](const std::string& what) {
+            err = path + ":" + std::to_string(lineno) + ": " + what;
+            return false;
+        };
+        while (std::getline(file, line)) {
+            lineno++;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty()) { scope = GLOBAL; continue; }
+            if (line[0] == '#') continue;
+            const std::string w0 = nth_word(line, 0);
+            bool ok = true;
+            switch (scope) {
+                case IMAGE:
+                    if (w0 == "PATH") textures.back().path = nth_word(line, 1);
+                    else return bad("unknown IMAGE definition command: " + w0);
+                    continue;
+                case MODEL:
+                    if (w0 == "PATH") models.back().path = nth_word(line, 1);
+                    else return bad("unknown MODEL definition command: " + w0);
+                    continue;
+                case MATERIAL: {
+                    AMaterial& m = materials.back();
+                    if (w0 == "TYPE") ok = stoi_ok(nth_word(line, 1), m.type);
+                    else if (w0 == "COLOR") ok = vec3(line, m.color);
+                    else if (w0 == "P1") ok = stof_ok(nth_word(line, 1), m.p1);
+                    else if (w0 == "P2") ok = stof_ok(nth_word(line, 1), m.p2);
+                    else if (w0 == "P3") ok = stof_ok(nth_word(line, 1), m.p3);
+                    else if (w0 == "TEXTURE") {
+                        if (m.images.size() >= 3) return bad("too many textures for material: " + m.name);
+                        m.images.push_back(nth_word(line, 1));
+                    } else return bad("unknown MATERIAL definition command: " + w0);
+                    if (!ok) return bad("bad number");
+                    continue;
+                }
+                case OBJECT:
+                    if (w0 == "MODEL") objects.back().model = nth_word(line, 1);
+                    else if (w0 == "MATERIAL") objects.back().material = nth_word(line, 1);
+                    else return bad("unknown OBJECT definition command: " + w0);
+                    continue;
+                case INSTANCE: {
+                    AInstance& in = instances.back();
+                    if (w0 == "OBJECT") in.object = nth_word(line, 1);
+                    else if (w0 == "POSITION") ok = vec3(line, in.pos);
+                    else if (w0 == "SCALE") ok = stof_ok(nth_word(line, 1), in.scale);
+                    else if (w0 == "ROTATION") ok = vec3(line, in.rot);
+                    else if (w0 == "IMPORTANCE_SAMPLE") in.importance = true;
+                    else return bad("unknown OBJECT INSTANCE definition command: " + w0);
+                    if (!ok) return bad("bad number");
+                    continue;
+                }
+                case SPHERE: {
+                    if (!enable_spheres) continue;  // sceneParser.cpp:285
+                    ASphere& s = spheres.back();
+                    if (w0 == "POSITION") ok = vec3(line, s.pos);
+                    else if (w0 == "RADIUS") ok = stof_ok(nth_word(line, 1), s.radius);
+                    else if (w0 == "MATERIAL") s.material = nth_word(line, 1);
+                    else return bad("unknown SPHERE definition command: " + w0);
+                    if (!ok) return bad("bad number");
+                    continue;
+                }
+                case GLOBAL: break;
+            }
+            if (w0 == "SET_OUTPUT_WIDTH") ok = stoi_ok(nth_word(line, 1), cam.width);
+            else if (w0 == "SET_OUTPUT_HEIGHT") ok = stoi_ok(nth_word(line, 1), cam.height);
+            else if (w0 == "SET_NUM_SAMPLES") ok = stoi_ok(nth_word(line, 1), cam.num_samples);
+            else if (w0 == "SET_CAM_POS") ok = vec3(line, cam.pos);
+            else if (w0 == "SET_CAM_ROTATION") ok = vec3(line, cam.rot);
+            else if (w0 == "SET_CAM_VEL") ok = vec3(line, cam.vel);
+            else if (w0 == "SET_CAM_ANGULAR_VEL") ok = vec3(line, cam.ang_vel);
+            else if (w0 == "SET_FOCAL_LENGTH") ok = stof_ok(nth_word(line, 1), cam.focal_length);
+            else if (w0 == "SET_APERTURE_RADIUS") ok = stof_ok(nth_word(line, 1), cam.aperture);
+            else if (w0 == "SET_FOCUS_DISTANCE") ok = stof_ok(nth_word(line, 1), cam.focus_distance);
+            else if (w0 == "SET_BACKGROUND") background = nth_word(line, 1);
+            else if (w0 == "ADD_OBJECT") { scope = INSTANCE; instances.emplace_back(); }
+            else if (w0 == "DEF_IMAGE") { scope = IMAGE; textures.emplace_back(); textures.back().name = nth_word(line, 1); }
+            else if (w0 == "DEF_MODEL") { scope = MODEL; models.emplace_back(); models.back().name = nth_word(line, 1); }
+            else if (w0 == "DEF_MATERIAL") { scope = MATERIAL; materials.emplace_back(); materials.back().name = nth_word(line, 1); }
+            else if (w0 == "DEF_OBJ") { scope = OBJECT; objects.emplace_back(); objects.back().name = nth_word(line, 1); }
+            else if (w0 == "ADD_SPHERE") { scope = SPHERE; spheres.emplace_back(); }
+            else return bad("unknown command: " + w0);
+            if (!ok) return bad("bad number");
+        }
+        return true;
+    }
+
+    template <class T>
+    T* by_name(std::vector<T>& v, const std::string& name) {
+        for (auto& e : v)
+            if (e.name == name) return &e;
+        return nullptr;
+    }
+    int material_index(const std::string& name) {
+        for (size_t i = 0; i < materials.size(); i++)
+            if (materials[i].name == name) return (int)i;
+        return -1;
+    }
+};
+
+std::string resolve_path(const std::string& p, const char* asset_root) {
+    if (!asset_root) return p;
+    size_t cut = p.find_last_of("/\\");
+    std::string base = cut == std::string::npos ? p : p.substr(cut + 1);
+    std::string root(asset_root);
+    if (!root.empty() && root.back() != '/') root.push_back('/');
+    return root + base;
+}
+
+// Vec3::colorToInt, vec3.h:111-116
+int32_t color_to_int(const V3& c) {
+    const int r = static_cast<int>(fminf(fmaxf(c.x * 255.0f, 0.0f), 255.0f));
+    const int g = static_cast<int>(fminf(fmaxf(c.y * 255.0f, 0.0f), 255.0f));
+    const int b = static_cast<int>(fminf(fmaxf(c.z * 255.0f, 0.0f), 255.0f));
+    return (r << 16) | (g << 8) | b;
+}
+
+rt_material blank_material() {
+    rt_material m;
+    memset(&m, 0, sizeof(m));
+    m.color = 0xFFFFFF;
+    m.image_offset[0] = m.image_offset[1] = m.image_offset[2] = -1;
+    return m;
+}
+
+// light list + marker removal, sceneParser.cpp:455-470
+void extract_lights(float* tris, size_t n_floats, std::vector<int32_t>& lights) {
+    lights.clear();
+    for (size_t i = 0; i < n_floats; i += RT_TRI_FLOATS) {
+        if (tris[i + 24] > 1000.0f) {
+            tris[i + 24] -= 1000.0f;
+            lights.push_back(static_cast<int32_t>(i));
+        }
+    }
+}
+
+int finish_geometry(rt_host_scene* sc, std::vector<float>& records, int max_depth, int min_tris) {
+    // prefix (sphere block) already in sc->tris
+    const size_t prefix = sc->tris.size();
+    sc->tris.resize(prefix + records.size());
+    if (!records.empty()) memcpy(sc->tris.data() + prefix, records.data(), records.size() * sizeof(float));
+    records.clear();
+    records.shrink_to_fit();
+    int rc = build_bvh(sc->tris.data() + prefix, sc->tris.size() - prefix, max_depth, min_tris, sc->nodes, &sc->bvh_depth);
+    if (rc != RT_OK) return rc;
+    extract_lights(sc->tris.data() + prefix, sc->tris.size() - prefix, sc->lights);
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_scene_last_error(void) { return g_err.c_str(); }
+
+void rt_host_free(void* p) { free(p); }
+
+void rt_scene_free(rt_host_scene* s) { delete s; }
+
+int rt_scene_get_desc(const rt_host_scene* s, rt_scene_desc* out) {
+    if (!s || !out) return fail("null argument");
+    const size_t prefix = s->n_spheres > 0 ? 1 + 5 * (size_t)s->n_spheres : 0;
+    out->tris = s->tris.data();
+    out->n_tri_floats = s->tris.size() - prefix;
+    out->n_spheres = s->n_spheres;
+    out->nodes = s->nodes.data();
+    out->n_nodes = (int32_t)s->nodes.size();
+    out->mats = s->mats.data();
+    out->n_mats = s->mats.size();
+    out->textures = s->textures.data();
+    out->n_tex_floats = s->textures.size();
+    out->light_tris = s->lights.data();
+    out->n_light_tris = (int32_t)s->lights.size();
+    return RT_OK;
+}
+
+int rt_scene_get_camera(const rt_host_scene* s, rt_camera* out) {
+    if (!s || !out) return fail("null argument");
+    *out = s->cam;
+    return RT_OK;
+}
+
+int rt_scene_bvh_depth(const rt_host_scene* s) { return s ? s->bvh_depth : -1; }
+
+int rt_bvh_build(float* tris, size_t n_floats, int max_depth, int min_tris, rt_bvh_node** out_nodes,
+                 int32_t* out_n_nodes) {
+    if (!tris && n_floats) return fail("null triangle array");
+    if (!out_nodes || !out_n_nodes) return fail("null output");
+    if (max_depth <= 0) max_depth = 16;
+    if (min_tris <= 0) min_tris = 4;
+    std::vector<rt_bvh_node> nodes;
+    int rc = build_bvh(tris, n_floats, max_depth, min_tris, nodes, nullptr);
+    if (rc != RT_OK) return rc;
+    rt_bvh_node* p = (rt_bvh_node*)malloc(nodes.size() * sizeof(rt_bvh_node));
+    if (!p) return fail("out of memory");
+    memcpy(p, nodes.data(), nodes.size() * sizeof(rt_bvh_node));
+    *out_nodes = p;
+    *out_n_nodes = (int32_t)nodes.size();
+    return RT_OK;
+}
+
+int rt_obj_load(const char* path, const float translation[3], float scale, const float rotation[3],
+                int material_index, float** out_tris, size_t* out_n_floats) {
+    if (!path || !translation || !rotation || !out_tris || !out_n_floats) return fail("null argument");
+    ParsedObj o;
+    std::string err;
+    if (!parse_obj(path, o, err)) return fail(err);
+    std::vector<float> rec;
+    emit_records(o, V3{translation[0], translation[1], translation[2]}, scale,
+                 V3{rotation[0], rotation[1], rotation[2]}, material_index, rec);
+    float* p = (float*)malloc(std::max<size_t>(rec.size(), 1) * sizeof(float));
+    if (!p) return fail("out of memory");
+    if (!rec.empty()) memcpy(p, rec.data(), rec.size() * sizeof(float));
+    *out_tris = p;
+    *out_n_floats = rec.size();
+    return RT_OK;
+}
+
+int rt_noise_texture(int w, int h, float* out_rgb) {
+    if (w <= 0 || h <= 0 || !out_rgb) return fail("bad noise texture arguments");
+    noise_generate(w, h, out_rgb);
+    return RT_OK;
+}
+
+int rt_image_load(const char* path, float** out_rgb, int* w, int* h) {
+    if (!path || !out_rgb || !w || !h) return fail("null argument");
+    Image img;
+    std::string err;
+    if (!load_image(path, img, err)) return fail(err);
+    float* p = (float*)malloc(img.rgb.size() * sizeof(float));
+    if (!p) return fail("out of memory");
+    memcpy(p, img.rgb.data(), img.rgb.size() * sizeof(float));
+    *out_rgb = p;
+    *w = img.w;
+    *h = img.h;
+    return RT_OK;
+}
+
+int rt_image_save(const char* path, const float* rgb, int w, int h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return fail("bad image arguments");
+    const std::string p(path);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("could not open for writing: " + p);
+    const size_t n = (size_t)w * h * 3;
+    if (ends_with(p, ".ppm")) {
+        fprintf(f, "P6\n%d %d\n255\n", w, h);
+        std::vector<unsigned char> img(n);
+        // texture.cpp:55: static_cast<unsigned char>(data[i] * 255), no clamp.
+        // (float -> int -> low 8 bits keeps that defined for out-of-range input.)
+        for (size_t i = 0; i < n; i++) img[i] = (unsigned char)(int)(rgb[i] * 255);
+        fwrite(img.data(), 1, n, f);
+    } else if (ends_with(p, ".pfm")) {
+        fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+        for (int y = h - 1; y >= 0; y--) fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f);
+    } else if (ends_with(p, ".hdr")) {
+        fprintf(f, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n", h, w);
+        for (size_t i = 0; i < (size_t)w * h; i++) {
+            const float r = rgb[i * 3], g = rgb[i * 3 + 1], b = rgb[i * 3 + 2];
+            const float m = fmaxf(r, fmaxf(g, b));
+            unsigned char px[4] = {0, 0, 0, 0};
+            if (m >= 1e-32f) {
+                int e;
+                const float norm = frexpf(m, &e) * 256.0f / m;
+                px[0] = (unsigned char)(r * norm);
+                px[1] = (unsigned char)(g * norm);
+                px[2] = (unsigned char)(b * norm);
+                px[3] = (unsigned char)(e + 128);
+            }
+            fwrite(px, 1, 4, f);
+        }
+    } else {
+        fclose(f);
+        return fail("unsupported output format (need .ppm/.pfm/.hdr): " + p);
+    }
+    fclose(f);
+    return RT_OK;
+}
+
+int rt_scene_from_records(const float* tris, size_t n_floats, const rt_material* mats, size_t n_mats,
+                          const float* textures, size_t n_tex_floats, int env_w, int env_h,
+                          int bvh_max_depth, int bvh_min_tris, rt_host_scene** out) {
+    if (!out || (!tris && n_floats) || (!mats && n_mats)) return fail("null argument");
+    if (n_floats % RT_TRI_FLOATS) return fail("triangle array length is not a multiple of 25");
+    if (bvh_max_depth <= 0) bvh_max_depth = 16;
+    if (bvh_min_tris <= 0) bvh_min_tris = 4;
+    rt_host_scene* sc = new rt_host_scene();
+    sc->cam.width = 512; sc->cam.height = 512; sc->cam.num_samples = 16;
+    sc->cam.focal_length = 1.0f; sc->cam.focus_distance = 4.0f;
+    sc->cam.env_width = env_w; sc->cam.env_height = env_h;
+    std::vector<float> rec(tris, tris + n_floats);
+    int rc = finish_geometry(sc, rec, bvh_max_depth, bvh_min_tris);
+    if (rc != RT_OK) { delete sc; return rc; }
+    sc->mats.assign(mats, mats + n_mats);
+    if (textures && n_tex_floats) sc->textures.assign(textures, textures + n_tex_floats);
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_load(const char* scene_path, const char* asset_root, const char* env_override,
+                  int enable_spheres, int bvh_max_depth, int bvh_min_tris, rt_host_scene** out) {
+    if (!scene_path || !out) return fail("null argument");
+    if (bvh_max_depth <= 0) bvh_max_depth = 16;
+    if (bvh_min_tris <= 0) bvh_min_tris = 4;
+    Parser P;
+    P.enable_spheres = enable_spheres != 0;
+    if (!P.parse(scene_path)) return fail(P.err);
+
+    rt_host_scene* sc = new rt_host_scene();
+    auto die = [&](const std::string& m) { delete sc; return fail(m); };
+
+    // ---- getTriangleData, sceneParser.cpp:398-475 (parsed meshes are cached per model) ----
+    std::vector<std::pair<std::string, ParsedObj>> cache;
+    std::vector<float> records;
+    for (const AInstance& in : P.instances) {
+        AObject* obj = P.by_name(P.objects, in.object);
+        if (!obj) return die("object not found: " + in.object);
+        int mi = P.material_index(obj->material);
+        if (mi < 0) return die("material not found: " + obj->material);
+        if (in.importance) mi += 1000;  // :408-410
+        AModel* model = P.by_name(P.models, obj->model);
+        if (!model) return die("model not found: " + obj->model);
+        const std::string path = resolve_path(model->path, asset_root);
+        const ParsedObj* po = nullptr;
+        for (auto& c : cache)
+            if (c.first == path) po = &c.second;
+        if (!po) {
+            cache.emplace_back(path, ParsedObj());
+            std::string err;
+            if (!parse_obj(path, cache.back().second, err)) return die(err);
+            po = &cache.back().second;
+        }
+        emit_records(*po, in.pos, in.scale, in.rot, mi, records);
+    }
+    // sphere prefix, sceneParser.cpp:423-453
+    if (P.enable_spheres) {
+        sc->n_spheres = (int)P.spheres.size();
+        if (sc->n_spheres > 0) {
+            sc->tris.push_back(static_cast<float>(P.spheres.size()) + 0.0001f);
+            for (const ASphere& s : P.spheres) {
+                const int mi = P.material_index(s.material);
+                if (mi < 0) return die("material not found: " + s.material);
+                sc->tris.push_back(s.pos.x);
+                sc->tris.push_back(s.pos.y);
+                sc->tris.push_back(s.pos.z);
+                sc->tris.push_back(s.radius);
+                sc->tris.push_back(static_cast<float>(mi) + 0.0001f);
+            }
+        }
+    }
+    int rc = finish_geometry(sc, records, bvh_max_depth, bvh_min_tris);
+    if (rc != RT_OK) { delete sc; return rc; }
+
+    // ---- getMaterialData, sceneParser.cpp:477-517 ----
+    sc->cam = P.cam;
+    std::vector<float>& pixels = sc->textures;
+    auto load_into_pool = [&](ATexture* t, const std::string& path, std::string& err) {
+        Image img;
+        if (!load_image(path, img, err)) return false;
+        t->offset = (int)pixels.size();
+        pixels.insert(pixels.end(), img.rgb.begin(), img.rgb.end());
+        t->loaded = true;
+        t->w = img.w;
+        t->h = img.h;
+        return true;
+    };
+    if (!P.background.empty()) {
+        ATexture* t = P.by_name(P.textures, P.background);
+        if (!t) return die("texture not found: " + P.background);
+        std::string err;
+        const std::string path = env_override ? std::string(env_override) : resolve_path(t->path, asset_root);
+        if (!load_into_pool(t, path, err)) return die(err);
+        sc->cam.env_width = t->w;
+        sc->cam.env_height = t->h;
+    }
+    for (const AMaterial& am : P.materials) {
+        rt_material m = blank_material();
+        m.type = (int8_t)am.type;
+        m.color = color_to_int(am.color);
+        m.p1 = am.p1; m.p2 = am.p2; m.p3 = am.p3;
+        for (size_t j = 0; j < am.images.size(); j++) {
+            const std::string& name = am.images[j];
+            if (name == "NOISE") {  // tryLoadTexture, sceneParser.cpp:520-534: always slot 0, 512x512
+                m.image_offset[0] = (int32_t)pixels.size();
+                m.image_width = 512;
+                m.image_height = 512;
+                const size_t base = pixels.size();
+                pixels.resize(base + (size_t)512 * 512 * 3);
+                noise_generate(512, 512, pixels.data() + base);
+                continue;
+            }
+            ATexture* t = P.by_name(P.textures, name);
+            if (!t) return die("texture not found: " + name);
+            if (!t->loaded) {
+                std::string err;
+                if (!load_into_pool(t, resolve_path(t->path, asset_root), err)) return die(err);
+            }
+            m.image_offset[j] = t->offset;
+            if (m.image_height != 0 && (m.image_height != t->h || m.image_width != t->w))
+                return die("textures must have the same dimensions for a material: " + am.name);
+            if (t->w > 65535 || t->h > 65535) return die("texture too large for 16-bit dimensions: " + name);
+            m.image_width = (uint16_t)t->w;
+            m.image_height = (uint16_t)t->h;
+        }
+        sc->mats.push_back(m);
+    }
+    *out = sc;
+    return RT_OK;
+}
+
+int rt_scene_synth_field(const char* obj_path, int instances, uint32_t seed, const char* env_path,
+                         int env_upsample, int bvh_max_depth, int bvh_min_tris, rt_host_scene** out) {
+    if (!obj_path || !out || instances <= 0) return fail("bad synth arguments");
+    if (bvh_max_depth <= 0) bvh_max_depth = 16;
+    if (bvh_min_tris <= 0) bvh_min_tris = 4;
+    ParsedObj po;
+    std::string err;
+    if (!parse_obj(obj_path, po, err)) return fail(err);
+    // object-space bounds to normalise the mesh to a unit footprint
+    float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+    for (size_t i = 0; i < po.v.size(); i += 3)
+        for (int c = 0; c < 3; c++) {
+            mn[c] = fminf(mn[c], po.v[i + c]);
+            mx[c] = fmaxf(mx[c], po.v[i + c]);
+        }
+    const float extent = fmaxf(mx[0] - mn[0], fmaxf(mx[1] - mn[1], mx[2] - mn[2]));
+    if (!(extent > 0)) return fail("degenerate mesh: " + std::string(obj_path));
+    // recentre the raw vertices so rotation happens about the mesh centre, base at y = 0
+    for (size_t i = 0; i < po.v.size(); i += 3) {
+        po.v[i] -= 0.5f * (mn[0] + mx[0]);
+        po.v[i + 1] -= mn[1];
+        po.v[i + 2] -= 0.5f * (mn[2] + mx[2]);
+    }
+    rt_host_scene* sc = new rt_host_scene();
+    const int side = (int)ceil(sqrt((double)instances));
+    const float cell = 1.6f;
+    std::mt19937 rng(seed);
+    auto uni = [&]() { return (float)(rng() >> 8) * (1.0f / 16777216.0f); };
+    std::vector<float> records;
+    records.reserve((size_t)instances * (po.idx.size() / 9) * RT_TRI_FLOATS + 2 * RT_TRI_FLOATS);
+    const float scale = 1.0f / extent;
+    for (int k = 0; k < instances; k++) {
+        const int gx = k % side, gz = k / side;
+        V3 pos;
+        pos.x = (gx - 0.5f * (side - 1)) * cell + (uni() - 0.5f) * 0.4f;
+        pos.y = 0.0f;
+        pos.z = -3.0f - gz * cell + (uni() - 0.5f) * 0.4f;
+        V3 rot{0.f, uni() * 6.2831853f, 0.f};
+        const int mat = 1 + (k % 3);
+        emit_records(po, pos, scale * (0.8f + 0.6f * uni()), rot, mat, records);
+    }
+    {   // ground quad (two triangles), material 0
+        const float hx = 0.5f * side * cell + 4.0f, z0 = 2.0f, z1 = -3.0f - side * cell - 4.0f;
+        const float q[4][3] = {{-hx, 0.f, z0}, {hx, 0.f, z0}, {hx, 0.f, z1}, {-hx, 0.f, z1}};
+        const int tri[2][3] = {{0, 1, 2}, {0, 2, 3}};
+        for (int t = 0; t < 2; t++) {
+            float r[RT_TRI_FLOATS] = {0};
+            for (int v = 0; v < 3; v++) {
+                for (int c = 0; c < 3; c++) r[v * 3 + c] = q[tri[t][v]][c];
+                r[9 + v * 3 + 1] = 1.0f;
+                r[18 + v * 2] = (q[tri[t][v]][0] + hx) / (2 * hx);
+                r[19 + v * 2] = (q[tri[t][v]][2] - z1) / (z0 - z1);
+            }
+            r[24] = 0.001f;
+            records.insert(records.end(), r, r + RT_TRI_FLOATS);
+        }
+    }
+    int rc = finish_geometry(sc, records, bvh_max_depth, bvh_min_tris);
+    if (rc != RT_OK) { delete sc; return rc; }
+    // materials: 0 ground Lambert, 1 Lambert, 2 glossy (type 0), 3 metal (type 4)
+    rt_material m = blank_material();
+    m.type = 3; m.color = color_to_int(V3{0.5f, 0.6f, 0.55f}); sc->mats.push_back(m);
+    m = blank_material(); m.type = 3; m.color = color_to_int(V3{1.0f, 0.52f, 0.12f}); sc->mats.push_back(m);
+    m = blank_material(); m.type = 0; m.color = color_to_int(V3{0.2f, 0.4f, 0.9f}); m.p1 = 0.3f; m.p2 = 0.1f; sc->mats.push_back(m);
+    m = blank_material(); m.type = 4; m.color = color_to_int(V3{0.9f, 0.9f, 0.9f}); m.p1 = 0.1f; sc->mats.push_back(m);
+    // camera looking down the field from above
+    sc->cam.width = 3840; sc->cam.height = 2160; sc->cam.num_samples = 128;
+    sc->cam.focal_length = 0.6f; sc->cam.aperture = 0.f; sc->cam.focus_distance = 4.f;
+    sc->cam.pos[0] = 0.f; sc->cam.pos[1] = 2.5f; sc->cam.pos[2] = 1.0f;
+    sc->cam.rot[0] = -0.35f; sc->cam.rot[1] = 0.f; sc->cam.rot[2] = 0.f;
+    if (env_path) {
+        Image img;
+        if (!load_image(env_path, img, err)) { delete sc; return fail(err); }
+        const int f = std::max(env_upsample, 1);
+        const int W = img.w * f, H = img.h * f;
+        sc->textures.resize((size_t)W * H * 3);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                memcpy(&sc->textures[((size_t)y * W + x) * 3], &img.rgb[((size_t)(y / f) * img.w + x / f) * 3], 12);
+        sc->cam.env_width = W;
+        sc->cam.env_height = H;
+    }
+    *out = sc;
+    return RT_OK;
+}
+
+}  // extern "C"
