@@ -22,7 +22,7 @@ $(LIBDIR)/librt_amd.so: $(PKG)/csrc/rt_core.hip $(wildcard $(PKG)/csrc/*.h) incl
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
 
 oracle: oracle/lib/librt_oracle.so
-oracle/lib/librt_oracle.so: oracle/rt_oracle.cpp include/rt.h
+oracle/lib/librt_oracle.so: oracle/rt_oracle.cpp oracle/rt_pmath_oracle.h include/rt.h
 	$(MAKE) -C oracle
 
 clean:

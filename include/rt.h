@@ -222,7 +222,9 @@ enum {
     RT_OP_TONEMAP = 9,       /* main.cu:23-38      in 3                     out 3                    */
     RT_OP_RNG = 10,          /* counter RNG        in 4 (as u32 bits: seed pixel sample dim) out 4 (u32 bits) */
     RT_OP_ENV_INDEX = 11,    /* main.cu:376-382    in 5: d envW envH        out 1 (int bits)         */
-    RT_OP_CAMERA_RAY = 12    /* main.cu:173-217    in 3 (u32 bits: x y sample), camera/flags/seed from params: out 6 */
+    RT_OP_CAMERA_RAY = 12,   /* main.cu:173-217    in 3 (u32 bits: x y sample), camera/flags/seed from params: out 6 */
+    RT_OP_PMATH = 13         /* portable libm      in 3: fn(int bits) x y   out 2
+                                fn 0 sincos(x) -> (sin, cos); 1 asin(x); 2 acos(x); 3 atan2(x, y); 4 log(x) */
 };
 /* params is only read by RT_OP_CAMERA_RAY (may be NULL otherwise). */
 int rt_debug_op(rt_context* ctx, int op, const float* in, size_t n, float* out,

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../include/rt.h"
+#include "rt_pmath_oracle.h"
 
 namespace {
 
@@ -99,9 +100,10 @@ struct Matrix {
 };
 inline Matrix rotation_matrix(const Vec3& v) {
     Matrix m;
-    float cosX = cosf(v.x), sinX = sinf(v.x);
-    float cosY = cosf(v.y), sinY = sinf(v.y);
-    float cosZ = cosf(v.z), sinZ = sinf(v.z);
+    float cosX, sinX, cosY, sinY, cosZ, sinZ;
+    pm::sincos(v.x, &sinX, &cosX);
+    pm::sincos(v.y, &sinY, &cosY);
+    pm::sincos(v.z, &sinZ, &cosZ);
     m.d[0] = cosY * cosZ;
     m.d[1] = -cosY * sinZ;
     m.d[2] = sinY;
@@ -176,7 +178,7 @@ struct Rng {
     float normal() {
         float u1 = uniform();
         float u2 = uniform();
-        return sqrtf(-2.0f * logf(u1)) * cosf(6.2831855f * u2);
+        return sqrtf(-2.0f * pm::log(u1)) * pm::cos(6.2831855f * u2);
     }
 };
 
@@ -483,10 +485,10 @@ Vec3 rand_sphere_vec(Rng& rng) {  // :130-140
     float r1 = rng.uniform();
     float r2 = rng.uniform();
     float theta = r1 * 2.0f * 3.14159f;
-    float phi = acosf(2.0f * r2 - 1.0f);
-    float x = sinf(phi) * cosf(theta);
-    float y = sinf(phi) * sinf(theta);
-    float z = cosf(phi);
+    float phi = pm::acos(2.0f * r2 - 1.0f);
+    float x = pm::sin(phi) * pm::cos(theta);
+    float y = pm::sin(phi) * pm::sin(theta);
+    float z = pm::cos(phi);
     return Vec3(x, y, z);
 }
 
@@ -661,8 +663,8 @@ bool material_reflect(const Scene& sc, const rt_material& m, Ray& ray, const Vec
 // Sphere::hitSphere, sphere.h:77-88 (declared bool, returns nothing: treated as "not terminated")
 void hit_sphere(const Scene& sc, const rt_material& m, Ray& ray, const Vec3& normal, const Vec3& hitPos, Rng& rng,
                 Counters& c) {
-    float u = atan2f(ray.direction.z, ray.direction.x) / (2.0f * 3.14159f) + 0.5f;
-    float v = -asinf(ray.direction.y) / (2.0f * 3.14159f) + 0.5f;
+    float u = pm::atan2(ray.direction.z, ray.direction.x) / (2.0f * 3.14159f) + 0.5f;
+    float v = -pm::asin(ray.direction.y) / (2.0f * 3.14159f) + 0.5f;
     Vec3 clr = texture_color(sc, m, u, v, 0, c);
     ray.diffuseMultiplier = ray.diffuseMultiplier * clr;
     ray.position = hitPos;
@@ -673,8 +675,8 @@ void hit_sphere(const Scene& sc, const rt_material& m, Ray& ray, const Vec3& nor
 
 // env lookup index, main.cu:376-382
 inline long long env_index(const Vec3& d, int W, int H) {
-    float bx = atan2f(d.z, d.x) / (2.0f * 3.14159f) + 0.5f;
-    float by = -asinf(d.y) / (2.0f * 3.14159f) + 0.5f;
+    float bx = pm::atan2(d.z, d.x) / (2.0f * 3.14159f) + 0.5f;
+    float by = -pm::asin(d.y) / (2.0f * 3.14159f) + 0.5f;
     bx *= W;
     by *= H;
     int ix = static_cast<int>(bx) % W;
@@ -699,8 +701,8 @@ inline void tone_map(Vec3& color) {
 inline Vec3 random_point_in_disk(const Vec3& up, const Vec3& right, float radius, Rng& rng) {
     float theta = 2.0f * 3.14159f * rng.uniform();
     float r = sqrtf(rng.uniform()) * radius;
-    float x = r * cosf(theta);
-    float y = r * sinf(theta);
+    float x = r * pm::cos(theta);
+    float y = r * pm::sin(theta);
     return up * y + right * x;
 }
 
@@ -1032,6 +1034,20 @@ int orc_debug_op(int op, const float* in, size_t n, float* out, const rt_render_
                 float* o = out + r * 6;
                 o[0] = ray.position.x; o[1] = ray.position.y; o[2] = ray.position.z;
                 o[3] = ray.direction.x; o[4] = ray.direction.y; o[5] = ray.direction.z;
+                break;
+            }
+            case RT_OP_PMATH: {
+                const float* q = in + r * 3;
+                float a = 0.f, b = 0.f;
+                switch ((int)f2u(q[0])) {
+                    case 0: pm::sincos(q[1], &a, &b); break;
+                    case 1: a = pm::asin(q[1]); break;
+                    case 2: a = pm::acos(q[1]); break;
+                    case 3: a = pm::atan2(q[1], q[2]); break;
+                    case 4: a = pm::log(q[1]); break;
+                    default: break;
+                }
+                out[r * 2] = a; out[r * 2 + 1] = b;
                 break;
             }
             default:

@@ -80,11 +80,11 @@ F_STATS = 1 << 8
 F_DEFAULT = F_SKYBOX | F_ANTIALIAS | F_DEFOCUS | F_BVH
 READ_RAW_SUM, READ_AVERAGE, READ_TONEMAPPED = 0, 1, 2
 (OP_TRI_INTERSECT, OP_AABB_DIST, OP_SPHERE, OP_FLOOR, OP_ITRI_PDF, OP_ITRI_SAMPLE, OP_ATTRACTOR_PDF,
- OP_ATTRACTOR_SAMPLE, OP_TONEMAP, OP_RNG, OP_ENV_INDEX, OP_CAMERA_RAY) = range(1, 13)
+ OP_ATTRACTOR_SAMPLE, OP_TONEMAP, OP_RNG, OP_ENV_INDEX, OP_CAMERA_RAY, OP_PMATH) = range(1, 14)
 OP_STRIDES = {OP_TRI_INTERSECT: (15, 4), OP_AABB_DIST: (12, 1), OP_SPHERE: (10, 7), OP_FLOOR: (7, 7),
               OP_ITRI_PDF: (15, 1), OP_ITRI_SAMPLE: (14, 3), OP_ATTRACTOR_PDF: (15, 1),
               OP_ATTRACTOR_SAMPLE: (14, 3), OP_TONEMAP: (3, 3), OP_RNG: (4, 4), OP_ENV_INDEX: (5, 1),
-              OP_CAMERA_RAY: (3, 6)}
+              OP_CAMERA_RAY: (3, 6), OP_PMATH: (3, 2)}
 TRI_FLOATS = 25
 
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback",

@@ -1,0 +1,700 @@
+// rt_device.h -- gfx950 device code of the path-tracing core: layouts, math,
+// counter RNG, intersection, BVH traversal and shading.
+//
+// Written for CDNA4 (wave64, LDS short stack, 16-byte vector loads); not a
+// translation of the reference's per-thread CUDA loop.  What each function
+// computes follows the reference (file:line cited), evaluated in the same
+// float operation order with FMA contraction OFF (-ffp-contract=off) so that
+// closest-hit ids agree bit for bit with the oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt.h"
+#include "rt_pmath.h"
+
+namespace rtd {
+
+// ------------------------------------------------------------------ layouts in HBM
+//
+// wide node  (64 B = 4 x float4, one per INNER node of the reference BVH; both child
+//             boxes + both child entries in one record, so one inner visit = one 64-B
+//             fetch instead of the reference's two 40-B child fetches, main.cu:268-269):
+//     q0 = (A.min.x, A.min.y, A.min.z, A.max.x)
+//     q1 = (A.max.y, A.max.z, B.min.x, B.min.y)
+//     q2 = (B.min.z, B.max.x, B.max.y, B.max.z)
+//     q3 = (entryA, entryB, refNodeId, 0)           as int bits
+//   entry >= 0 : index of an inner node in `wide`;  entry < 0 : ~entry = index in `leaves`
+// leaf       (8 B int2): (first triangle id, triangle count)   [main.cu:247-248]
+// tri hot    (48 B = 3 x float4): v0, e1 = v1 - v0, e2 = v2 - v0 (the single subtraction
+//             of main.cu:43-44 done at upload, bit-identical), w = (.., .., matId)
+//     h0 = (v0.x, v0.y, v0.z, e1.x)  h1 = (e1.y, e1.z, e2.x, e2.y)  h2 = (e2.z, 0, 0, matId bits)
+// tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
+// material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
+// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
+// sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
+struct Scene {
+    const float4* wide;
+    const int2* leaves;
+    const float4* tri_hot;
+    const float4* tri_cold;
+    const float4* mats;
+    const float4* lights;
+    const float4* spheres;
+    const float* tex;
+    long long n_tex;
+    int n_tris;
+    int n_mats;
+    int n_lights;
+    int n_spheres;
+    int root_entry;  // entry of node 0
+    int has_root;    // n_nodes > 0
+    float root_min[3];
+    float root_max[3];
+};
+
+// Per-call parameters (kernel argument, lives in SGPRs / kernarg segment).
+struct Params {
+    int width, height;       // full image
+    int rows;                // accumulator rows of this call (band-packed)
+    int band_rows, band_stride, band_index;
+    int sample_begin, sample_count;
+    int max_bounces;
+    unsigned flags;
+    unsigned seed;
+    float focal, aperture, focus_dist;
+    float cam_pos[3], cam_rot[3], cam_vel[3], cam_angvel[3];
+    int static_basis;        // angular velocity == 0: basis below is valid for every sample
+    float up[3], right[3], forward[3];
+    int env_w, env_h;
+    float bg[3];
+    float bg_brightness;
+    int tiles_x, n_tiles;
+};
+
+#define RT_STACK_ENTRIES 24   // per-lane LDS stack depth (a depth-D tree needs D entries here)
+#define RT_WAVES_PER_BLOCK 4
+
+// ------------------------------------------------------------------ float3 helpers (vec3.h:14-197)
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float len2(f3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// Vec3::normalize, vec3.h:89-105: multiply by 1/length, zero vector if that is not > 0.
+__device__ __forceinline__ f3 normalize(f3 a) {
+    float invlen = 1.0f / sqrtf(len2(a));
+    if (invlen > 0) return mk(a.x * invlen, a.y * invlen, a.z * invlen);
+    return mk(0.f, 0.f, 0.f);
+}
+// static Vec3::normalize(Vec3&), vec3.h:97-105: leaves the vector untouched if 1/len is not > 0.
+__device__ __forceinline__ f3 normalize_keep(f3 a) {
+    float invlen = 1.0f / sqrtf(len2(a));
+    if (invlen > 0) return mk(a.x * invlen, a.y * invlen, a.z * invlen);
+    return a;
+}
+// Vec3::reflect, vec3.h:42-47
+__device__ __forceinline__ f3 reflect(f3 v, f3 n) {
+    float d = 2.0f * dot(v, n);
+    return mk(v.x - d * n.x, v.y - d * n.y, v.z - d * n.z);
+}
+// Vec3::refract, vec3.h:49-62
+__device__ __forceinline__ f3 refract(f3 v, f3 n, float eta) {
+    float cos_theta = fminf(-dot(v, n), 1.0f);
+    f3 perp = mk((v.x + n.x * cos_theta) * eta, (v.y + n.y * cos_theta) * eta, (v.z + n.z * cos_theta) * eta);
+    float k = -sqrtf(fabsf(1.0f - len2(perp)));
+    return mk(perp.x + n.x * k, perp.y + n.y * k, perp.z + n.z * k);
+}
+__device__ __forceinline__ f3 lerp3(f3 a, f3 b, float t) {  // vec3.h:125-131
+    return mk(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z));
+}
+__device__ __forceinline__ f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ------------------------------------------------------------------ counter RNG (rt.h)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Sequential view of one (pixel, sample) stream: draws are taken from consecutive
+// dimensions; a Philox block (4 dims) is generated when first touched.
+struct Rng {
+    uint32_t seed, pixel, sample;
+    uint32_t dim;
+    uint32_t block;  // block held in w, 0xffffffff = none
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ void init(uint32_t s, uint32_t p, uint32_t k) {
+        seed = s; pixel = p; sample = k; dim = 0; block = 0xffffffffu;
+    }
+    __device__ __forceinline__ void seek(uint32_t d) { dim = d; }
+    __device__ __forceinline__ uint32_t raw() {
+        const uint32_t b = dim >> 2;
+        if (b != block) {
+            uint32_t o[4];
+            philox4x32_10(pixel, sample, b, RT_RNG_TAG, seed, RT_RNG_KEY1, o);
+            w0 = o[0]; w1 = o[1]; w2 = o[2]; w3 = o[3];
+            block = b;
+        }
+        const uint32_t k = dim & 3u;
+        dim++;
+        return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+    }
+    __device__ __forceinline__ float uniform() { return (float)((raw() >> 8) + 1u) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ float normal() {
+        const float u1 = uniform();
+        const float u2 = uniform();
+        return sqrtf(-2.0f * pm::log(u1)) * pm::cos(6.2831855f * u2);
+    }
+};
+
+// ------------------------------------------------------------------ counters
+struct Counters {
+    uint32_t paths, rays, inner, leaf, tri, hits, texels, lights;
+    __device__ __forceinline__ void clear() { paths = rays = inner = leaf = tri = hits = texels = lights = 0; }
+};
+
+// ------------------------------------------------------------------ intersection
+
+// rayTriangleIntersect, main.cu:41-70, on the pre-subtracted edges.
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, f3& outPos) {
+    const float epsilon = 1e-9f;
+    const f3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    if (det > -epsilon && det < epsilon) return false;
+    const float inv_det = 1.0f / det;
+    const f3 s = o - v0;
+    const float u = inv_det * dot(s, p);
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(s, e1);
+    const float v = inv_det * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = inv_det * dot(e2, q);
+    if (t > epsilon) {
+        outPos = o + d * t;
+        return true;
+    }
+    return false;
+}
+
+// AABBIntersectDistance, main.cu:73-117, with 1/dir hoisted out (same value).
+__device__ __forceinline__ float aabb_distance(f3 o, f3 inv, f3 mn, f3 mx) {
+    if (o.x >= mn.x && o.x <= mx.x && o.y >= mn.y && o.y <= mx.y && o.z >= mn.z && o.z <= mx.z) return 0.0f;
+    float tmin = 0.0f;
+    float tmax = 1e13f;
+    float t1 = (mn.x - o.x) * inv.x;
+    float t2 = (mx.x - o.x) * inv.x;
+    tmin = fmaxf(tmin, fminf(t1, t2));
+    tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = (mn.y - o.y) * inv.y;
+    t2 = (mx.y - o.y) * inv.y;
+    tmin = fmaxf(tmin, fminf(t1, t2));
+    tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = (mn.z - o.z) * inv.z;
+    t2 = (mx.z - o.z) * inv.z;
+    tmin = fmaxf(tmin, fminf(t1, t2));
+    tmax = fminf(tmax, fmaxf(t1, t2));
+    if (tmax < tmin) return 1e13f;
+    if (tmin < 0.0f) return 1e13f;
+    return tmin;
+}
+
+// Sphere::intersectSphere, sphere.h:30-46
+__device__ __forceinline__ bool intersect_sphere(f3 o, f3 d, f3 c, float radius, f3& out_pos, f3& out_normal) {
+    const f3 fromSphere = o - c;
+    const float b = 2.0f * dot(fromSphere, d);
+    if (b > 0) return false;
+    const float cc = len2(fromSphere) - radius * radius;
+    const float disc = b * b - 4.0f * cc;
+    if (disc < 0) return false;
+    const float t = (-b - sqrtf(disc)) / 2.0f;
+    out_pos = o + d * t;
+    out_normal = normalize(out_pos - c);
+    return true;
+}
+
+// Floor::intersection, floor.h:8-21
+__device__ __forceinline__ bool intersect_floor(f3 o, f3 d, float elevation, f3& pos, f3& normal) {
+    if (d.y >= 0) return false;
+    const float t = (elevation - o.y) / d.y;
+    if (t < 0) return false;
+    pos = o + d * t;
+    normal = mk(0.f, 1.f, 0.f);
+    return true;
+}
+
+// ImportanceTri::pdf_value, importanceTri.h:67-76 (normal, area precomputed at upload
+// with the constructor's operations, importanceTri.h:19-25)
+__device__ __forceinline__ float itri_pdf(f3 origin, f3 direction, f3 p1, f3 e1, f3 e2, f3 normal, float area) {
+    f3 hit;
+    if (!ray_triangle(origin, direction, p1, e1, e2, hit)) return 0.0f;
+    const f3 to = hit - origin;
+    const float distance_squared = len2(to);
+    const float cos_theta = fabsf(dot(normalize(to), normal));
+    return distance_squared / (cos_theta * area);
+}
+
+// ImportanceTri::generate_random, importanceTri.h:79-90
+__device__ __forceinline__ f3 itri_sample(f3 origin, float r1, float r2, f3 p1, f3 p2, f3 p3) {
+    const float su = sqrtf(r1);
+    const float b0 = 1.0f - su;
+    const float b1 = r2 * su;
+    const float b2 = 1.0f - b0 - b1;
+    const f3 random_point = p1 * b0 + p2 * b1 + p3 * b2;
+    return normalize(random_point - origin);
+}
+
+// RayAttractor, rayAttractor.h:11-61 (vestigial in the reference; library function only)
+struct Attractor {
+    f3 pos, normal, u, v;
+    float area;
+    __device__ __forceinline__ void init(f3 p, f3 uu, f3 vv) {
+        pos = p;
+        area = sqrtf(len2(cross(uu, vv))) * 0.25f;
+        u = normalize(uu);
+        v = normalize(vv);
+        normal = normalize(cross(u, v));
+    }
+    __device__ __forceinline__ bool intersect(f3 origin, f3 direction, f3& hit) const {
+        const float denom = dot(normal, direction);
+        if (fabs((double)denom) < 1e-12) return false;
+        const float t = dot(pos - origin, normal) / denom;
+        if (t <= 0) return false;
+        hit = origin + direction * t;
+        const float u_pos = dot(hit - pos, u);
+        const float v_pos = dot(hit - pos, v);
+        return u_pos >= -0.5f && u_pos <= 0.5f && v_pos >= -0.5f && v_pos <= 0.5f;
+    }
+    __device__ __forceinline__ float pdf(f3 origin, f3 direction) const {
+        f3 hit;
+        if (!intersect(origin, direction, hit)) return 0.0f;
+        const f3 to = hit - origin;
+        const float distance_squared = len2(to);
+        const float cos_theta = fabsf(dot(normalize(to), normal));
+        return distance_squared / (cos_theta * area);
+    }
+    __device__ __forceinline__ f3 sample(f3 origin, float r1, float r2) const {
+        return pos + u * (r1 - 0.5f) + v * (r2 - 0.5f) - origin;
+    }
+};
+
+// ------------------------------------------------------------------ traversal (main.cu:221-301)
+//
+// Visit order contract of the reference: root tested once (< 1e12); at an inner node
+// both child boxes are tested, the far child is pushed first and the near child last,
+// each only if dist^2 < minDistSqr AT PUSH TIME; ties (dA^2 == dB^2) pop B first; no
+// re-test at pop; leaf triangles in array order; strict '<' keeps the first-tested
+// triangle on equal distance.  The near child is kept in a register instead of being
+// pushed and popped again (same order, half the LDS traffic).
+//
+// stk: this lane's column of the wave's LDS stack; entry i lives at stk[i * 64].
+template <bool STATS>
+__device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool use_bvh, int* stk, int& hitTri,
+                                              float& minD2, f3& hitPos, Counters& cn) {
+    hitTri = -1;
+    minD2 = 1e12f;
+    if (STATS) cn.rays++;
+    if (!use_bvh) {  // main.cu:285-301
+        for (int i = 0; i < sc.n_tris; i++) {
+            const float4 h0 = sc.tri_hot[3 * (size_t)i], h1 = sc.tri_hot[3 * (size_t)i + 1], h2 = sc.tri_hot[3 * (size_t)i + 2];
+            if (STATS) cn.tri++;
+            f3 pos;
+            if (ray_triangle(o, d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
+                const float nd = len2(pos - o);
+                if (nd < minD2) { minD2 = nd; hitPos = pos; hitTri = i; }
+            }
+        }
+        return;
+    }
+    if (!sc.has_root) return;
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
+    // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
+    if (!(aabb_distance(o, inv, ld3(sc.root_min), ld3(sc.root_max)) <= 1e12f)) return;
+    int sp = 0;
+    int cur = sc.root_entry;
+    for (;;) {
+        if (cur >= 0) {
+            if (STATS) cn.inner++;
+            const float4* w = sc.wide + 4 * (size_t)cur;
+            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+            float dA = aabb_distance(o, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+            float dB = aabb_distance(o, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+            dA = dA * dA;
+            dB = dB * dB;
+            const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
+            const bool aNear = dA < dB;
+            const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
+            const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
+            if (dFar < minD2) { stk[sp * 64] = eFar; sp++; }
+            if (dNear < minD2) { cur = eNear; continue; }
+        } else {
+            if (STATS) cn.leaf++;
+            const int2 lf = sc.leaves[~cur];
+            const int end = lf.x + lf.y;
+            for (int i = lf.x; i < end; i++) {
+                const float4* t = sc.tri_hot + 3 * (size_t)i;
+                const float4 h0 = t[0], h1 = t[1], h2 = t[2];
+                if (STATS) cn.tri++;
+                f3 pos;
+                if (ray_triangle(o, d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
+                    const float nd = len2(pos - o);
+                    if (nd < minD2) { minD2 = nd; hitPos = pos; hitTri = i; }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stk[sp * 64];
+    }
+}
+
+// ------------------------------------------------------------------ shading (material.h)
+
+struct PathState {
+    f3 o, d;        // Ray::position, direction        ray.h:13-14
+    f3 thr;         // Ray::diffuseMultiplier          ray.h:15
+    f3 emission;    // Ray::emission                   ray.h:16
+    float ri;       // Ray::refractiveIndex            ray.h:17
+    float volDensity;  // Ray::volumeDensity           ray.h:18
+    f3 volColor;    // Ray::volumeColor                ray.h:19
+};
+
+__device__ __forceinline__ f3 fetch_texel(const Scene& sc, long long i) {
+    if (sc.n_tex < 3) return mk(0.f, 0.f, 0.f);
+    const long long hi = sc.n_tex - 3;
+    i = i < 0 ? 0 : (i > hi ? hi : i);  // only the final index is clamped
+    return mk(sc.tex[i], sc.tex[i + 1], sc.tex[i + 2]);
+}
+
+// Material::randSphereVec, material.h:130-140 (same body: Vec3::randSphere, Sphere::randSphereVec)
+__device__ __forceinline__ f3 rand_sphere_vec(Rng& rng) {
+    const float r1 = rng.uniform();
+    const float r2 = rng.uniform();
+    const float theta = r1 * 2.0f * 3.14159f;
+    const float phi = pm::acos(2.0f * r2 - 1.0f);
+    float sp, cp, st, ct;
+    pm::sincos(phi, &sp, &cp);
+    pm::sincos(theta, &st, &ct);
+    return mk(sp * ct, sp * st, cp);
+}
+
+// Material::randCosineHemisphere, material.h:152-161
+__device__ __forceinline__ f3 rand_cosine_hemisphere(f3 normal, Rng& rng) {
+    const f3 s = rand_sphere_vec(rng);
+    const float cos_theta = dot(s, normal);
+    if (cos_theta > 0.0f) return s * sqrtf(cos_theta);
+    return s * -1.0f * sqrtf(-cos_theta);
+}
+
+// barycentric + interpolateNormal, material.h:110-128, on the stored edges
+__device__ __forceinline__ f3 barycentric(f3 a, f3 e1, f3 e2, f3 pos) {
+    const f3 v2 = pos - a;
+    const float d00 = dot(e1, e1);
+    const float d01 = dot(e1, e2);
+    const float d11 = dot(e2, e2);
+    const float d20 = dot(v2, e1);
+    const float d21 = dot(v2, e2);
+    const float denom = d00 * d11 - d01 * d01;
+    const float v = (d11 * d20 - d01 * d21) / denom;
+    const float w = (d00 * d21 - d01 * d20) / denom;
+    const float u = 1.0f - v - w;
+    return mk(u, v, w);
+}
+
+struct HitFrame {
+    f3 normal;
+    float u, v;
+    int mat;
+};
+
+__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int tri, f3 hitPos) {  // material.h:44-62
+    const float4* t = sc.tri_hot + 3 * (size_t)tri;
+    const float4 h0 = t[0], h1 = t[1], h2 = t[2];
+    const float4* c = sc.tri_cold + 4 * (size_t)tri;
+    const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    const f3 bary = barycentric(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), hitPos);
+    const f3 n0 = mk(c0.x, c0.y, c0.z), n1 = mk(c0.w, c1.x, c1.y), n2 = mk(c1.z, c1.w, c2.x);
+    HitFrame f;
+    f.normal = normalize(n0 * bary.x + n1 * bary.y + n2 * bary.z);
+    // uv0 = (c2.y, c2.z) uv1 = (c2.w, c3.x) uv2 = (c3.y, c3.z)
+    f.u = bary.x * c2.y + bary.y * c2.w + bary.z * c3.y;
+    f.v = bary.x * c2.z + bary.y * c3.x + bary.z * c3.z;
+    f.mat = __float_as_int(c3.w);
+    return f;
+}
+
+// Material::reflect, material.h:41-106.  Returns true when the path terminates.
+template <bool STATS>
+__device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, Rng& rng,
+                                               Counters& cn) {
+    const HitFrame hf = hit_frame(sc, tri, hitPos);
+    const f3 normal = hf.normal;
+    int type = 127;  // out-of-range material id -> "the color of error"
+    f3 clr = mk(0.f, 0.f, 0.f);
+    float p1 = 0.f, p2 = 0.f;
+    int off0 = -1, off1 = -1, off2 = -1, tw = 0, th = 0;
+    if (hf.mat >= 0 && hf.mat < sc.n_mats) {
+        const float4* m = sc.mats + 3 * (size_t)hf.mat;
+        const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+        type = __float_as_int(m0.x);
+        clr = mk(m0.y, m0.z, m0.w);
+        p1 = m1.x;
+        p2 = m1.y;
+        off0 = __float_as_int(m1.w);
+        off1 = __float_as_int(m2.x);
+        off2 = __float_as_int(m2.y);
+        tw = __float_as_int(m2.z);
+        th = __float_as_int(m2.w);
+    }
+    f3 clr0 = clr;
+    if (off0 >= 0) {  // getTextureColor, material.h:163-175
+        const float px = hf.u * (float)tw;
+        const float py = hf.v * (float)th;
+        const long long i = (long long)off0 + 3LL * (int)px + 3LL * tw * (int)py;
+        clr0 = fetch_texel(sc, i);
+        if (STATS) cn.texels++;
+    }
+    // images 2 and 3 are fetched and never used by the reference (material.h:70-75): only counted.
+    if (STATS) cn.texels += (off1 >= 0) + (off2 >= 0);
+
+    switch (type) {
+        case 0: {  // reflectType0, material.h:182-202
+            ray.o = hitPos;
+            if (rng.uniform() < p1) {
+                ray.thr = ray.thr * mk(0.95f, 0.95f, 0.95f);
+                ray.d = reflect(ray.d, normal);
+            } else {
+                ray.thr = ray.thr * clr;
+                const float g0 = rng.normal();
+                const float g1 = rng.normal();
+                const float g2 = rng.normal();
+                ray.d = reflect(ray.d, normalize(normal + mk(g0, g1, g2) * p2));
+            }
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        case 1: {  // reflectType1, material.h:205-213; always terminates (:82-84)
+            if (dot(ray.d, normal) > 0.0f) ray.emission = mk(0.f, 0.f, 0.f);
+            else ray.emission = clr * p1;
+            return true;
+        }
+        case 2: {  // reflectType2, material.h:216-254
+            ray.o = hitPos;
+            const bool fromOutside = dot(ray.d, normal) < 0.0f;
+            const float oldRI = ray.ri;
+            const float newRI = fromOutside ? oldRI + p1 : oldRI - p1;
+            const f3 normal2 = fromOutside ? normal : normal * -1.0f;
+            const float ri = oldRI / newRI;
+            const float cos_theta = fminf(-dot(ray.d, normal2), 1.0f);
+            const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool will_refract = ri * sin_theta <= 1.0f;
+            if (will_refract) {
+                float r0 = (1 - ri) / (1 + ri);
+                r0 = r0 * r0;
+                // std::pow(float,int) is a double pow in the reference; x^5 by double products.
+                const double x = (double)(1 - cos_theta);
+                const double x2 = x * x;
+                r0 = (float)((double)r0 + (double)(1 - r0) * (x2 * x2 * x));
+                if (r0 > rng.uniform()) will_refract = false;
+            }
+            if (will_refract) {
+                ray.d = refract(ray.d, normal2, ri);
+                ray.ri = newRI;
+            } else {
+                ray.d = reflect(ray.d, normal2);  // (three discarded normals: dims left unused)
+            }
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        case 3: {  // reflectType3, material.h:257-266
+            const f3 normal2 = (dot(normal, ray.d) < 0.0f) ? normal : (normal * -1.0f);
+            ray.thr = ray.thr * clr0;
+            ray.o = hitPos;
+            ray.d = normalize(normal2 + rand_sphere_vec(rng));
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        case 4: {  // reflectType4, material.h:269-277
+            ray.thr = ray.thr * clr;
+            ray.o = hitPos;
+            ray.d = reflect(ray.d, normal);
+            ray.d = ray.d + rand_sphere_vec(rng) * p1;
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        case 5: {  // reflectType5, material.h:280-336
+            const f3 normal2 = (dot(normal, ray.d) < 0.0f) ? normal : (normal * -1.0f);
+            ray.o = hitPos;
+            f3 outgoing;
+            bool sampledLight = false;
+            if (sc.n_lights > 0 && rng.uniform() < 0.5f) {
+                const uint32_t pick = rng.raw() % (uint32_t)sc.n_lights;
+                const float4* L = sc.lights + 5 * (size_t)pick;
+                const float4 l0 = L[0], l3 = L[3], l4 = L[4];
+                const float r1 = rng.uniform();
+                const float r2 = rng.uniform();
+                outgoing = itri_sample(hitPos, r1, r2, mk(l0.x, l0.y, l0.z), mk(l3.y, l3.z, l3.w), mk(l4.x, l4.y, l4.z));
+                sampledLight = true;
+            } else {
+                outgoing = rand_cosine_hemisphere(normal2, rng);
+            }
+            float cos_theta = dot(normal2, outgoing);
+            if (cos_theta <= 0.0f && sampledLight) {
+                outgoing = rand_cosine_hemisphere(normal2, rng);
+                cos_theta = dot(normal2, outgoing);
+            }
+            if (cos_theta < 0.0f) cos_theta = 0.0f;
+            const float inv_pi = 1.0f / 3.14159f;
+            const float pdf_cos = cos_theta * inv_pi;
+            float pdf_light = 0.0f;
+            for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323
+                const float4* L = sc.lights + 5 * (size_t)i;
+                const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+                if (STATS) cn.lights++;
+                pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x),
+                                      mk(l2.y, l2.z, l2.w), l3.x) / (float)sc.n_lights;
+            }
+            const float pdf = (sc.n_lights > 0) ? (0.5f * pdf_cos + 0.5f * pdf_light) : pdf_cos;
+            if (pdf <= 1e-12f) {
+                ray.thr = mk(0.f, 0.f, 0.f);
+                return false;
+            }
+            ray.thr = ray.thr * clr * (pdf_cos / pdf);
+            ray.d = outgoing;
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        case 6: {  // reflectType6, material.h:339-352 (state only; scattering is compiled out, config.h:9)
+            if (dot(normal, ray.d) < 0.0f) {
+                ray.volDensity += p1;
+                ray.volColor = clr;
+            } else {
+                ray.volDensity -= p1;
+            }
+            ray.o = hitPos;
+            ray.o = ray.o + ray.d * 1e-5f;
+            return false;
+        }
+        default:
+            ray.emission = mk(1.0f, 0.0f, 1.0f);
+            return true;
+    }
+}
+
+// Sphere::hitSphere, sphere.h:77-88
+template <bool STATS>
+__device__ __forceinline__ void shade_sphere(const Scene& sc, PathState& ray, f3 normal, f3 hitPos, int mat, Rng& rng,
+                                             Counters& cn) {
+    const float u = pm::atan2(ray.d.z, ray.d.x) / (2.0f * 3.14159f) + 0.5f;
+    const float v = -pm::asin(ray.d.y) / (2.0f * 3.14159f) + 0.5f;
+    f3 clr = mk(1.0f, 0.0f, 1.0f);
+    if (mat >= 0 && mat < sc.n_mats) {
+        const float4* m = sc.mats + 3 * (size_t)mat;
+        const float4 m1 = m[1], m2 = m[2];
+        const int off0 = __float_as_int(m1.w), tw = __float_as_int(m2.z), th = __float_as_int(m2.w);
+        if (off0 >= 0) {
+            const float px = u * (float)tw;
+            const float py = v * (float)th;
+            clr = fetch_texel(sc, (long long)off0 + 3LL * (int)px + 3LL * tw * (int)py);
+            if (STATS) cn.texels++;
+        }
+    }
+    ray.thr = ray.thr * clr;
+    ray.o = hitPos;
+    ray.d = normalize(normal + rand_sphere_vec(rng));
+    ray.o = ray.o + ray.d * 1e-5f;
+}
+
+// env lookup, main.cu:376-382 -> float index of the texel
+__device__ __forceinline__ long long env_index(f3 d, int W, int H) {
+    float bx = pm::atan2(d.z, d.x) / (2.0f * 3.14159f) + 0.5f;
+    float by = -pm::asin(d.y) / (2.0f * 3.14159f) + 0.5f;
+    bx *= (float)W;
+    by *= (float)H;
+    const int ix = (int)bx % W;
+    const int iy = (int)by % H;
+    return ((long long)iy * W + ix) * 3;
+}
+
+// toneMap, main.cu:23-38
+__device__ __forceinline__ f3 tone_map(f3 c) {
+    const float exposure_factor = powf(2.0f, -0.8f);
+    c.x = c.x * (c.x * 2.51f + 0.03f) / (c.x * (c.x * 2.43f + 0.59f) + 0.14f) * exposure_factor;
+    c.y = c.y * (c.y * 2.51f + 0.03f) / (c.y * (c.y * 2.43f + 0.59f) + 0.14f) * exposure_factor;
+    c.z = c.z * (c.z * 2.51f + 0.03f) / (c.z * (c.z * 2.43f + 0.59f) + 0.14f) * exposure_factor;
+    const float inv_gamma = 1.0f / 2.2f;
+    return mk(powf(c.x, inv_gamma), powf(c.y, inv_gamma), powf(c.z, inv_gamma));
+}
+
+// ------------------------------------------------------------------ camera (main.cu:173-217)
+__device__ __forceinline__ void camera_ray(const Params& P, int x, int y, Rng& rng, f3& origin, f3& dir) {
+    const float sx = (float)x / (float)P.width - 0.5f;
+    const float sy = -(float)y / (float)P.height + 0.5f;
+    rng.seek(RT_RNG_DIM_CAMERA);
+    const float t = rng.uniform();
+    const f3 pos0 = ld3(P.cam_pos);
+    const f3 camPos = lerp3(pos0, pos0 + ld3(P.cam_vel), t);
+    f3 up, right, forward;
+    if (P.static_basis) {
+        up = ld3(P.up);
+        right = ld3(P.right);
+        forward = ld3(P.forward);
+    } else {  // Matrix::rotationMatrix, matrix.h:14-37 at the lerped Euler angles
+        const f3 rot0 = ld3(P.cam_rot);
+        const f3 e = lerp3(rot0, rot0 + ld3(P.cam_angvel), t);
+        float cX, sX, cY, sY, cZ, sZ;
+        pm::sincos(e.x, &sX, &cX);
+        pm::sincos(e.y, &sY, &cY);
+        pm::sincos(e.z, &sZ, &cZ);
+        const float m0 = cY * cZ, m1 = -cY * sZ;
+        const float m3 = cX * sZ + sX * sY * cZ, m4 = cX * cZ - sX * sY * sZ;
+        const float m6 = sX * sZ - cX * sY * cZ, m7 = sX * cZ + cX * sY * sZ;
+        const float m2 = sY, m5 = -sX * cY, m8 = cX * cY;
+        // rot * (0,1,0) and rot * (1,0,0) with the full three-term sums of matrix.h:48-54
+        up = normalize_keep(mk(m0 * 0.0f + m1 * 1.0f + m2 * 0.0f, m3 * 0.0f + m4 * 1.0f + m5 * 0.0f, m6 * 0.0f + m7 * 1.0f + m8 * 0.0f));
+        right = normalize_keep(mk(m0 * 1.0f + m1 * 0.0f + m2 * 0.0f, m3 * 1.0f + m4 * 0.0f + m5 * 0.0f, m6 * 1.0f + m7 * 0.0f + m8 * 0.0f));
+        forward = normalize(cross(up, right));
+    }
+    float aa1 = 0.0f, aa2 = 0.0f;
+    if (P.flags & RT_F_ANTIALIAS) {
+        aa1 = rng.uniform() - 0.5f;
+        aa2 = rng.uniform() - 0.5f;
+    }
+    const f3 s = forward * P.focal + right * (sx + aa1 / (float)P.width) + up * (sy + aa2 / (float)P.height);
+    dir = normalize(s);
+    origin = camPos;
+    if (P.aperture > 1e-5f && (P.flags & RT_F_DEFOCUS)) {  // randomPointInDisk, main.cu:119-125
+        rng.seek(RT_RNG_DIM_LENS);
+        const float theta = 2.0f * 3.14159f * rng.uniform();
+        const float r = sqrtf(rng.uniform()) * (P.aperture * 0.5f);
+        float st, ct;
+        pm::sincos(theta, &st, &ct);
+        const float lx = r * ct;
+        const float ly = r * st;
+        const f3 lensOffset = up * ly + right * lx;
+        const f3 focusPoint = camPos + dir * P.focus_dist;
+        origin = camPos + lensOffset;
+        dir = normalize(focusPoint - origin);
+    }
+}
+
+}  // namespace rtd
