@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--bounces", type=int, default=6)
     ap.add_argument("--partition", choices=["samples", "rows"], default="samples")
+    ap.add_argument("--mode", choices=["wavefront", "megakernel"], default="wavefront")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=0, help="use the synthetic instanced field instead of --scene")
@@ -85,6 +86,8 @@ def main():
     r = rt.Renderer(local_rank)
     r.upload(scene)
     p = rt.default_params(scene.camera, spp=spp, width=W, height=H, max_bounces=args.bounces)
+    if args.mode == "megakernel":
+        p.flags |= rt.F_MEGAKERNEL
     if world > 1:
         D.partition_params(p, rank, world, args.partition, spp)
     rows = rt.band_rows_of(p)
@@ -110,6 +113,10 @@ def main():
     p_stats = rt.RenderParams.from_buffer_copy(p)
     p_stats.flags |= rt.F_STATS
     st_counts = step(p_stats)
+    # one untimed launch with per-launch HIP events around the trace kernel (wavefront mode): its summed duration
+    p_prof = rt.RenderParams.from_buffer_copy(p)
+    p_prof.flags |= rt.F_PROFILE
+    st_prof = step(p_prof)
 
     for _ in range(args.warmup):
         step(p)
@@ -137,9 +144,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         mrays = total_rays / (elapsed / args.steps) / 1e6
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = float(np.mean(kernel_ms))          # all kernels of one frame (HIP events on the render stream)
         abytes = algorithmic_bytes(st_counts, rows * W)
-        achieved = abytes / (k_ms * 1e-3) / 1e9
+        if args.mode == "wavefront" and st_prof.trace_launches > 0:
+            # dominant kernel = rt_trace_kernel: its algorithmic bytes (nodes + leaves + triangles) over the
+            # summed duration of its launches in one frame, per launch on both sides of the ratio
+            dom_kernel = "rt_trace_kernel"
+            dom_bytes = 56 * st_counts.inner_visits + 8 * st_counts.leaf_visits + 36 * st_counts.tri_tests
+            dom_ms = st_prof.trace_ms
+            launches = st_prof.trace_launches
+        else:
+            dom_kernel, dom_bytes, dom_ms, launches = "rt_render_kernel", abytes, k_ms, 1
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.synth_instances == 0 and args.scene == "scene.txt" and (W, H, spp) == (1920, 1080, 64):
@@ -161,13 +177,17 @@ def main():
             "dtype": "f32",
             "data": "bundled scene geometry/textures, synthetic camera batch" if args.synth_instances == 0 else "synthetic",
             "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp, "max_bounces": args.bounces,
-                       "partition": "none" if world == 1 else args.partition,
+                       "partition": "none" if world == 1 else args.partition, "mode": args.mode,
+                       "wavefront_iterations": int(st_counts.iterations),
                        "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
                        "spp_per_sec_1080p": round(total_paths / (elapsed / args.steps) / (1920 * 1080), 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "rt_render_kernel", "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(abytes),
+                         "kernel": dom_kernel, "launches_per_step": launches,
+                         "avg_launch_ms": round(dom_ms / launches, 4),
+                         "algorithmic_bytes_per_launch": int(dom_bytes / launches),
+                         "frame_kernels_ms": round(k_ms, 3), "frame_algorithmic_bytes": int(abytes),
+                         "frame_algorithmic_GBps": round(abytes / (k_ms * 1e-3) / 1e9, 1),
                          "bytes_per_ray": round(abytes / max(st_counts.rays, 1), 1)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -116,6 +116,8 @@ enum {
     RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9  (reserved, rejected) */
     RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14 (reserved, rejected) */
     RT_F_STATS = 1 << 8,        /* count rays / node visits / triangle tests */
+    RT_F_MEGAKERNEL = 1 << 9,   /* one fused persistent kernel (lane = pixel) instead of the wavefront pipeline */
+    RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every trace-kernel launch (rt_render_stats.trace_ms) */
     RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
 };
 
@@ -147,6 +149,9 @@ typedef struct rt_render_stats {
     uint64_t hits;          /* bounces that hit a triangle or sphere */
     uint64_t texel_fetches; /* material texel fetches + env fetches */
     uint64_t light_tests;   /* ImportanceTri::pdf_value calls, material.h:315-323 */
+    double trace_ms;        /* RT_F_PROFILE: summed HIP-event time of the rt_trace_kernel launches */
+    uint32_t iterations;    /* wavefront iterations (logic + trace launch pairs) of this call */
+    uint32_t trace_launches; /* launches covered by trace_ms */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };

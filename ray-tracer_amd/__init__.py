@@ -67,7 +67,8 @@ class RenderParams(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("rays", C.c_uint64),
                 ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64)]
+                ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64),
+                ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -77,6 +78,8 @@ assert C.sizeof(BvhNode) == 40 and C.sizeof(Material) == 48 and C.sizeof(Camera)
 
 F_SKYBOX, F_ANTIALIAS, F_DEFOCUS, F_BVH, F_SPHERES, F_VOLUME, F_RAYMARCH = 1, 2, 4, 8, 16, 32, 64
 F_STATS = 1 << 8
+F_MEGAKERNEL = 1 << 9
+F_PROFILE = 1 << 10
 F_DEFAULT = F_SKYBOX | F_ANTIALIAS | F_DEFOCUS | F_BVH
 READ_RAW_SUM, READ_AVERAGE, READ_TONEMAPPED = 0, 1, 2
 (OP_TRI_INTERSECT, OP_AABB_DIST, OP_SPHERE, OP_FLOOR, OP_ITRI_PDF, OP_ITRI_SAMPLE, OP_ATTRACTOR_PDF,
@@ -101,6 +104,8 @@ _ip = C.POINTER(C.c_int32)
 
 def _load(name: str) -> C.CDLL:
     path = os.path.join(LIB_DIR, name)
+    if name == "librt_amd.so" and os.environ.get("RT_AMD_LIB"):  # A/B builds of the HIP core (tools/ab_bench.sh)
+        path = os.environ["RT_AMD_LIB"]
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `make` (or __graft_entry__.build()) first; "
                            "there is no fallback path")

@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,8 +40,11 @@ __device__ __forceinline__ int row_to_y(const Params& P, int r) {
     return (k * P.band_stride + P.band_index) * P.band_rows + (r - k * P.band_rows);
 }
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1  // second __launch_bounds__ argument = waves per SIMD the register allocator must allow
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_render_kernel(Scene sc, Params P, float* __restrict__ accum,
+__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK, RT_MIN_WAVES) void rt_render_kernel(Scene sc, Params P, float* __restrict__ accum,
                                                                               unsigned int* __restrict__ tile_counter,
                                                                               unsigned long long* __restrict__ stats) {
     __shared__ int lds_stack[RT_WAVES_PER_BLOCK][RT_STACK_ENTRIES][64];
@@ -165,6 +169,323 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_render_kernel(Scen
     }
 }
 
+// =============================================================================== wavefront pipeline
+//
+// Slot = one pixel of this call (8x8-tiled order so that neighbouring slots are neighbouring
+// pixels).  A slot runs its samples one after the other (sample order per pixel = the
+// reference's loop main.cu:178, so the per-pixel float sum is bit-identical), one ray in
+// flight per slot.  Per iteration:
+//   rt_logic_kernel : thread = slot.  Consumes the slot's hit record (shade / environment /
+//                     accumulate), regenerates a camera ray when the path ended, and appends
+//                     the next ray to a compacted ray queue (wave-aggregated atomic).
+//   rt_trace_kernel : persistent waves; lanes pull rays from the queue with a shared cursor
+//                     and REFILL as soon as enough lanes have finished, so a wave is not held
+//                     hostage by its longest traversal.  Per-lane short stack in LDS.
+// Slot state (SoA, 16-byte records, coalesced in the logic kernel):
+//   st_dir[slot] = (d.xyz, refractiveIndex)      st_thr[slot] = (throughput.xyz, sample<<8 | bounce)
+//   st_col[slot] = (colour sum.xyz, phase)       hits[slot]   = (hitPos.xyz, tri id | -1 miss | -2-i sphere i)
+// Ray queue entry = 2 x float4: (o.xyz, slot) (d.xyz, 0).
+struct Wavefront {
+    float4* st_dir;
+    float4* st_thr;
+    float4* st_col;
+    float4* hits;
+    float4* rayq;
+    unsigned int* qcount;  // [2] rays appended in iteration parity
+    unsigned int* cursor;  // [2] rays handed out by the trace kernel
+    int n_slots;
+};
+
+enum { SLOT_NEW = 0, SLOT_WAIT = 1, SLOT_DONE = 2 };
+
+#define RT_LOGIC_BLOCK 1024  // one queue-append atomic per 1024 slots (same-address atomics serialise at ~12 ns each)
+
+template <bool STATS>
+__global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Params P, Wavefront wf, float* __restrict__ accum, int iter,
+                                                                   unsigned long long* __restrict__ stats) {
+    __shared__ unsigned int wave_count[RT_LOGIC_BLOCK / 64];
+    __shared__ unsigned int block_base;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int par = iter & 1;
+    if (slot == 0) {  // the other parity's counters were last used by the previous trace launch
+        wf.qcount[par ^ 1] = 0;
+        wf.cursor[par ^ 1] = 0;
+    }
+    Counters cn;
+    cn.clear();
+    bool emit = false;
+    f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
+    if (slot < wf.n_slots) {
+        const int tile = slot >> 6, within = slot & 63;
+        const int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+        const int x = tx * 8 + (within & 7);
+        const int r = ty * 8 + (within >> 3);
+        const bool in_image = x < P.width && r < P.rows;
+        int phase;
+        f3 color = mk(0.f, 0.f, 0.f);
+        if (iter == 0) {
+            phase = in_image ? SLOT_NEW : SLOT_DONE;
+            if (!in_image) wf.st_col[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(SLOT_DONE));
+        } else {
+            const float4 c = wf.st_col[slot];
+            color = mk(c.x, c.y, c.z);
+            phase = __float_as_int(c.w);
+        }
+        if (phase != SLOT_DONE) {
+            const int y = row_to_y(P, r);
+            const uint32_t pixel = (uint32_t)(x + y * P.width);  // main.cu:171
+            int k = 0, bounce = 0;
+            PathState ray;
+            ray.emission = mk(0.f, 0.f, 0.f);
+            ray.volDensity = 0.f;  // type-6 state is never read while volume scattering is off (config.h:9)
+            ray.volColor = mk(1.f, 1.f, 1.f);
+            Rng rng;
+            bool need_regen = (phase == SLOT_NEW);
+            if (phase == SLOT_WAIT) {  // one iteration of the bounce loop after its closest-hit query, main.cu:303-388
+                const float4 sd = wf.st_dir[slot], stt = wf.st_thr[slot], h = wf.hits[slot];
+                ray.d = mk(sd.x, sd.y, sd.z);
+                ray.ri = sd.w;
+                ray.thr = mk(stt.x, stt.y, stt.z);
+                const int packed = __float_as_int(stt.w);
+                k = packed >> 8;
+                bounce = packed & 0xff;
+                ray.o = mk(0.f, 0.f, 0.f);
+                rng.init(P.seed, pixel, (uint32_t)(P.sample_begin + k - 1));
+                rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce);
+                const f3 hitPos = mk(h.x, h.y, h.z);
+                const int tri = __float_as_int(h.w);
+                bool terminated = false;
+                if (tri <= -2) {  // sphere -2-i, main.cu:337-344
+                    const int si = -2 - tri;
+                    const float4 s0 = sc.spheres[2 * si];
+                    const int mat = __float_as_int(sc.spheres[2 * si + 1].x);
+                    if (STATS) cn.hits++;
+                    shade_sphere<STATS>(sc, ray, normalize(hitPos - mk(s0.x, s0.y, s0.z)), hitPos, mat, rng, cn);
+                } else if (tri >= 0) {
+                    if (STATS) cn.hits++;
+                    terminated = shade_triangle<STATS>(sc, ray, hitPos, tri, rng, cn);
+                    if (terminated) {  // main.cu:357-360
+                        const f3 e = ray.emission * ray.thr;
+                        color.x += e.x; color.y += e.y; color.z += e.z;
+                    } else {
+                        ray.d = normalize_keep(ray.d);  // main.cu:361
+                    }
+                } else {  // main.cu:374-387
+                    f3 e;
+                    if ((P.flags & RT_F_SKYBOX) && P.env_w > 0) {
+                        const long long envI = env_index(ray.d, P.env_w, P.env_h);
+                        if (STATS) cn.texels++;
+                        e = fetch_texel(sc, envI) * ray.thr * P.bg_brightness;
+                    } else {
+                        e = ld3(P.bg) * ray.thr * P.bg_brightness;
+                    }
+                    color.x += e.x; color.y += e.y; color.z += e.z;
+                    terminated = true;
+                }
+                bounce++;
+                if (bounce >= P.max_bounces) terminated = true;  // path exhausted: contributes 0
+                if (terminated) need_regen = true;
+                else { emit = true; ro = ray.o; rd = ray.d; }
+            }
+            if (need_regen) {
+                if (P.max_bounces <= 0) {  // the bounce loop never runs: every sample contributes 0
+                    if (STATS) cn.paths += P.sample_count - k;
+                    k = P.sample_count;
+                }
+                if (k < P.sample_count) {  // camera sample k, main.cu:178-217
+                    rng.init(P.seed, pixel, (uint32_t)(P.sample_begin + k));
+                    k++;
+                    camera_ray(P, x, y, rng, ray.o, ray.d);
+                    ray.thr = mk(1.f, 1.f, 1.f);
+                    ray.ri = 1.0f;
+                    bounce = 0;
+                    if (STATS) cn.paths++;
+                    emit = true; ro = ray.o; rd = ray.d;
+                } else {  // all samples of this pixel done: one plain add, this thread owns the pixel
+                    float* a = accum + ((size_t)r * P.width + x) * 3;
+                    a[0] += color.x;
+                    a[1] += color.y;
+                    a[2] += color.z;
+                    phase = SLOT_DONE;
+                }
+            }
+            if (emit) {
+                phase = SLOT_WAIT;
+                wf.st_dir[slot] = make_float4(rd.x, rd.y, rd.z, ray.ri);
+                wf.st_thr[slot] = make_float4(ray.thr.x, ray.thr.y, ray.thr.z, __int_as_float((k << 8) | bounce));
+            }
+            wf.st_col[slot] = make_float4(color.x, color.y, color.z, __int_as_float(phase));
+        }
+    }
+    // append to the ray queue: wave ballots -> LDS prefix over the block's waves -> ONE atomic per block
+    const unsigned long long mask = __ballot(emit);
+    if (lane == 0) wave_count[wave] = (unsigned int)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < RT_LOGIC_BLOCK / 64; w++) {
+            const unsigned int c = wave_count[w];
+            wave_count[w] = total;
+            total += c;
+        }
+        block_base = total ? atomicAdd(&wf.qcount[par], total) : 0u;
+    }
+    __syncthreads();
+    if (emit) {
+        const unsigned int pos = block_base + wave_count[wave] + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        wf.rayq[2 * (size_t)pos] = make_float4(ro.x, ro.y, ro.z, __int_as_float(slot));
+        wf.rayq[2 * (size_t)pos + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
+    }
+    if (STATS) {
+        uint32_t v[4] = {cn.paths, cn.hits, cn.texels, cn.lights};
+        const int idx[4] = {0, 5, 6, 7};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned long long t = v[i];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+            if (lane == 0 && t) atomicAdd(&stats[idx[i]], t);
+        }
+    }
+}
+
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16  // refill the wave when at least this many lanes are idle
+#endif
+
+// Persistent closest-hit kernel.  queue: n rays (2 x float4 each); results go to hits[slot].
+// counts (optional): per-slot {inner, leaf, tri} visit counts for the rt_trace_rays test hook.
+template <bool STATS>
+__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_trace_kernel(Scene sc, const float4* __restrict__ rayq,
+                                                                             const unsigned int* __restrict__ n_rays_ptr,
+                                                                             unsigned int* __restrict__ cursor,
+                                                                             float4* __restrict__ hits, unsigned flags,
+                                                                             int* __restrict__ counts,
+                                                                             unsigned long long* __restrict__ stats) {
+    __shared__ int lds_stack[RT_WAVES_PER_BLOCK][RT_STACK_ENTRIES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int* stk = &lds_stack[wave][0][lane];
+    const unsigned int n_rays = *n_rays_ptr;
+    const bool use_bvh = (flags & RT_F_BVH) != 0;
+    const bool spheres_on = (flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
+    Counters cn, tot;
+    cn.clear();
+    tot.clear();
+    Trav t;
+    t.cur = RT_TRAV_DONE;
+    bool has = false;
+    int slot = 0;
+    // Work distribution: the queue is cut into chunks.  Wave w owns chunk w outright (no atomic),
+    // further chunks come from ONE shared cursor (a same-address atomic costs ~12 ns serialised,
+    // so chunks are large when the queue is long).  Waves whose first chunk lies beyond the queue
+    // leave at once.
+    const unsigned int n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
+    const unsigned int gw = blockIdx.x * RT_WAVES_PER_BLOCK + wave;
+#ifndef RT_DIST
+#define RT_DIST 0
+#endif
+#ifndef RT_CHUNK_MAX
+#define RT_CHUNK_MAX 512
+#endif
+    unsigned int chunk = 64;
+#if RT_DIST == 0
+    while (chunk < RT_CHUNK_MAX && (unsigned long long)chunk * n_waves * 2 <= n_rays) chunk *= 2;
+#endif
+    unsigned int next = gw * chunk;                                  // wave-uniform: next ray of the local chunk
+    unsigned int end = next + chunk < n_rays ? next + chunk : n_rays;  // wave-uniform: end of the local chunk
+    bool exhausted = next >= n_rays;
+    if (exhausted) next = end = 0;
+#if RT_DIST == 1
+    unsigned int my_chunk = gw;  // static interleave: chunks gw, gw + n_waves, ...
+#endif
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && (n_idle >= RT_REFILL_MIN || n_idle == 64)) {
+            if (next >= end) {  // local chunk used up: take another one
+#if RT_DIST == 1
+                my_chunk += n_waves;
+                const unsigned long long start = (unsigned long long)my_chunk * chunk;
+#else
+                unsigned int c = 0;
+                if (lane == 0) c = atomicAdd(cursor, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                const unsigned long long start = ((unsigned long long)n_waves + c) * chunk;
+#endif
+                if (start >= n_rays) exhausted = true;
+                else { next = (unsigned int)start; end = next + chunk < n_rays ? next + chunk : n_rays; }
+            }
+            if (!exhausted) {
+                const unsigned int avail = end - next;
+                const unsigned int rank = (unsigned int)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!has && rank < avail) {
+                    const unsigned int idx = next + rank;
+                    const float4 r0 = rayq[2 * (size_t)idx], r1 = rayq[2 * (size_t)idx + 1];
+                    slot = __float_as_int(r0.w);
+                    if (STATS) { cn.clear(); tot.rays++; }
+                    trav_begin(sc, t, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+                    if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
+                    has = true;
+                }
+                next += (unsigned int)n_idle < avail ? (unsigned int)n_idle : avail;
+            }
+        }
+        if (!__any(has)) break;  // nothing in flight: the queue is exhausted as well
+        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn);
+        if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
+            int tri = t.hitTri;
+            if (spheres_on) {
+                f3 sPos;
+                const int si = trav_spheres(sc, t, sPos);
+                if (si >= 0) { tri = -2 - si; t.hitPos = sPos; }
+            }
+            hits[slot] = make_float4(t.hitPos.x, t.hitPos.y, t.hitPos.z, __int_as_float(tri));
+            if (STATS) {
+                if (counts) { counts[slot * 3] = (int)cn.inner; counts[slot * 3 + 1] = (int)cn.leaf; counts[slot * 3 + 2] = (int)cn.tri; }
+                tot.inner += cn.inner; tot.leaf += cn.leaf; tot.tri += cn.tri;
+            }
+            has = false;
+        }
+    }
+    if (STATS && stats) {
+        uint32_t v[4] = {tot.rays, tot.inner, tot.leaf, tot.tri};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned long long s = v[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&stats[1 + i], s);
+        }
+    }
+}
+
+// Post-pass of the rt_trace_rays hook: distance and interpolated shading normal of each hit.
+__global__ void rt_hitinfo_kernel(Scene sc, const float* __restrict__ rays, const float4* __restrict__ hits, size_t n, int* prim,
+                                  float* t, float* hit_pos, float* normal3) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hits[i];
+    const int tri = __float_as_int(h.w);
+    const f3 o = ld3(rays + i * 6), pos = mk(h.x, h.y, h.z);
+    if (prim) prim[i] = tri;
+    if (t) t[i] = tri >= 0 ? sqrtf(len2(pos - o)) : -1.0f;  // sqrt of the closest-hit metric, main.cu:257
+    if (hit_pos) { hit_pos[i * 3] = tri >= 0 ? pos.x : 0.f; hit_pos[i * 3 + 1] = tri >= 0 ? pos.y : 0.f; hit_pos[i * 3 + 2] = tri >= 0 ? pos.z : 0.f; }
+    if (normal3) {
+        f3 nn = mk(0.f, 0.f, 0.f);
+        if (tri >= 0) nn = hit_frame(sc, tri, pos).normal;
+        normal3[i * 3] = nn.x; normal3[i * 3 + 1] = nn.y; normal3[i * 3 + 2] = nn.z;
+    }
+}
+
+// rays (n x 6 floats) -> queue entries with slot = ray index
+__global__ void rt_fill_queue_kernel(const float* __restrict__ rays, size_t n, float4* __restrict__ rayq) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rayq[2 * i] = make_float4(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2], __int_as_float((int)i));
+    rayq[2 * i + 1] = make_float4(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5], 0.f);
+}
+
 // avg + tone map of main.cu:392-406 applied to raw sums
 __global__ void rt_resolve_kernel(const float* __restrict__ accum, float* __restrict__ out, size_t n_pixels,
                                   float samples, int mode) {
@@ -176,41 +497,6 @@ __global__ void rt_resolve_kernel(const float* __restrict__ accum, float* __rest
         if (mode == RT_READ_TONEMAPPED) c = tone_map(c);
     }
     out[i * 3] = c.x; out[i * 3 + 1] = c.y; out[i * 3 + 2] = c.z;
-}
-
-__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_trace_kernel(Scene sc, const float* __restrict__ rays,
-                                                                             size_t n, unsigned flags, int* prim,
-                                                                             float* t, float* hit_pos, float* normal3,
-                                                                             int* counts) {
-    __shared__ int lds_stack[RT_WAVES_PER_BLOCK][RT_STACK_ENTRIES][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int* stk = &lds_stack[wave][0][lane];
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const f3 o = ld3(rays + i * 6), d = ld3(rays + i * 6 + 3);
-    Counters cn;
-    cn.clear();
-    int hitTri;
-    float minD2;
-    f3 hitPos = mk(0.f, 0.f, 0.f);
-    trace_closest<true>(sc, o, d, (flags & RT_F_BVH) != 0, stk, hitTri, minD2, hitPos, cn);
-    if (prim) prim[i] = hitTri;
-    if (t) t[i] = hitTri >= 0 ? sqrtf(minD2) : -1.0f;
-    if (hit_pos) {
-        hit_pos[i * 3] = hitTri >= 0 ? hitPos.x : 0.f;
-        hit_pos[i * 3 + 1] = hitTri >= 0 ? hitPos.y : 0.f;
-        hit_pos[i * 3 + 2] = hitTri >= 0 ? hitPos.z : 0.f;
-    }
-    if (normal3) {
-        f3 nn = mk(0.f, 0.f, 0.f);
-        if (hitTri >= 0) nn = hit_frame(sc, hitTri, hitPos).normal;
-        normal3[i * 3] = nn.x; normal3[i * 3 + 1] = nn.y; normal3[i * 3 + 2] = nn.z;
-    }
-    if (counts) {
-        counts[i * 3] = (int)cn.inner;
-        counts[i * 3 + 1] = (int)cn.leaf;
-        counts[i * 3 + 2] = (int)cn.tri;
-    }
 }
 
 __global__ void rt_shade_kernel(Scene sc, const float* __restrict__ in, size_t n, unsigned seed, float* __restrict__ out) {
@@ -366,7 +652,7 @@ struct rt_context {
     // scene (device)
     bool has_scene = false;
     Scene sc{};
-    void* d_wide = nullptr; void* d_leaves = nullptr; void* d_hot = nullptr; void* d_cold = nullptr;
+    void* d_items = nullptr; void* d_cold = nullptr;
     void* d_mats = nullptr; void* d_lights = nullptr; void* d_spheres = nullptr; void* d_tex = nullptr;
     int bvh_depth = 0;
 
@@ -378,8 +664,16 @@ struct rt_context {
     int acc_rows = 0, acc_width = 0;
     int64_t samples_done = 0;
 
-    unsigned int* d_tile_counter = nullptr;
+    unsigned int* d_tile_counter = nullptr;  // [0] megakernel tile counter, [4..5] qcount, [6..7] cursor, [8] trace hook count
     unsigned long long* d_stats = nullptr;
+
+    // wavefront state (sized to the largest call so far)
+    Wavefront wf{};
+    void* d_wf = nullptr;
+    int wf_slots = 0;
+    int trace_occ = 0;       // resident trace blocks per CU
+    std::vector<hipEvent_t> ev_pool;
+    unsigned int* h_pinned = nullptr;
 };
 
 namespace {
@@ -397,7 +691,7 @@ int set_err(rt_context* c, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(rt_context* c) {
-    void** ptrs[] = {&c->d_wide, &c->d_leaves, &c->d_hot, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
+    void** ptrs[] = {&c->d_items, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -520,6 +814,7 @@ int rt_create(rt_context** out, int device_id) {
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipMalloc((void**)&c->d_tile_counter, 256) == hipSuccess &&
+              hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault) == hipSuccess &&
               hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         rt_destroy(c);
@@ -536,6 +831,9 @@ void rt_destroy(rt_context* c) {
     free_scene(c);
     if (c->d_accum_own) (void)hipFree(c->d_accum_own);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_wf) (void)hipFree(c->d_wf);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -566,24 +864,25 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     const float* tris = s->tris + prefix;
     const int ntri = (int)(s->n_tri_floats / RT_TRI_FLOATS);
 
-    // ---- BVH: reference AoS nodes -> wide inner records + leaf table (same topology, numbering, leaf order)
+    // ---- BVH + triangles: reference AoS nodes / 25-float records -> one item stream
+    //      (same topology, BFS numbering of the inner nodes, leaf order of the triangles)
     const int nn = s->n_nodes;
-    std::vector<int> entry(nn);
-    int n_inner = 0, n_leaf = 0;
+    std::vector<int> inner_index(nn, -1);
+    int n_inner = 0;
     for (int i = 0; i < nn; i++) {
         const rt_bvh_node& n = s->nodes[i];
         if (n.child_a == -1) {
             if (n.tri_offs < 0 || n.tri_len < 0 || n.tri_offs % RT_TRI_FLOATS || n.tri_len % RT_TRI_FLOATS ||
                 (size_t)n.tri_offs + (size_t)n.tri_len > s->n_tri_floats)
                 return set_err(c, RT_ERR_INVALID, "BVH leaf " + std::to_string(i) + " has a bad triangle range");
-            entry[i] = ~(n_leaf++);
         } else {
             // children must come after the parent (BFS numbering): guarantees a finite, acyclic walk
             if (n.child_a <= i || n.child_a >= nn || n.child_b <= i || n.child_b >= nn)
                 return set_err(c, RT_ERR_INVALID, "BVH node " + std::to_string(i) + " has bad child indices");
-            entry[i] = n_inner++;
+            inner_index[i] = n_inner++;
         }
     }
+    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     std::vector<int> depth(nn, 0);
     int max_depth = 0;
     for (int i = 0; i < nn; i++) {
@@ -597,42 +896,53 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (max_depth > RT_STACK_ENTRIES)
         return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
-    std::vector<float> wide((size_t)std::max(n_inner, 1) * 16, 0.f);
-    std::vector<int32_t> leaves((size_t)std::max(n_leaf, 1) * 2, 0);
+    auto entry_of = [&](int node) -> int {
+        const rt_bvh_node& n = s->nodes[node];
+        if (n.child_a != -1) return inner_index[node];
+        if (n.tri_len == 0) return RT_TRAV_EMPTY;
+        return n_inner + n.tri_offs / RT_TRI_FLOATS;
+    };
+    std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
+    std::vector<float> cold((size_t)std::max(ntri, 1) * 16, 0.f);
+    for (int i = 0; i < ntri; i++) {
+        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
+        float* h = &items[((size_t)n_inner + i) * 16];
+        float* cd = &cold[(size_t)i * 16];
+        const int mat = static_cast<int>(t[24]);  // main.cu:353
+        h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
+        h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
+        h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
+        h[9] = i2f(0); h[10] = i2f(mat); h[11] = 0.f;
+        for (int k = 0; k < 15; k++) cd[k] = t[9 + k];
+        cd[15] = i2f(mat);
+    }
+    std::vector<char> covered(std::max(ntri, 1), 0);
     for (int i = 0; i < nn; i++) {
         const rt_bvh_node& n = s->nodes[i];
         if (n.child_a == -1) {
-            const int li = ~entry[i];
-            leaves[2 * (size_t)li] = n.tri_offs / RT_TRI_FLOATS;
-            leaves[2 * (size_t)li + 1] = n.tri_len / RT_TRI_FLOATS;
+            const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+            for (int k = 0; k < cnt; k++) {
+                // a triangle in two leaves would need two "last" flags: the reference builder never does that
+                if (covered[first + k]) return set_err(c, RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
+                covered[first + k] = 1;
+                int flags = 0;
+                if (k == cnt - 1) flags |= 1;
+                if (k == 0) flags |= 2;
+                items[((size_t)n_inner + first + k) * 16 + 9] = i2f(flags);
+            }
         } else {
-            float* w = &wide[(size_t)entry[i] * 16];
+            float* w = &items[(size_t)inner_index[i] * 16];
             const rt_bvh_node& A = s->nodes[n.child_a];
             const rt_bvh_node& B = s->nodes[n.child_b];
             w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_min[2];
             w[3] = A.bbox_max[0]; w[4] = A.bbox_max[1]; w[5] = A.bbox_max[2];
             w[6] = B.bbox_min[0]; w[7] = B.bbox_min[1]; w[8] = B.bbox_min[2];
             w[9] = B.bbox_max[0]; w[10] = B.bbox_max[1]; w[11] = B.bbox_max[2];
-            w[12] = i2f(entry[n.child_a]);
-            w[13] = i2f(entry[n.child_b]);
+            w[12] = i2f(entry_of(n.child_a));
+            w[13] = i2f(entry_of(n.child_b));
             w[14] = i2f(i);
             w[15] = 0.f;
         }
-    }
-
-    // ---- triangles: hot (v0, e1, e2) / cold (normals, uvs, material id)
-    std::vector<float> hot((size_t)std::max(ntri, 1) * 12, 0.f), cold((size_t)std::max(ntri, 1) * 16, 0.f);
-    for (int i = 0; i < ntri; i++) {
-        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
-        float* h = &hot[(size_t)i * 12];
-        float* cd = &cold[(size_t)i * 16];
-        const int mat = static_cast<int>(t[24]);  // main.cu:353
-        h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
-        h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
-        h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
-        h[9] = 0.f; h[10] = 0.f; h[11] = i2f(mat);
-        for (int k = 0; k < 15; k++) cd[k] = t[9 + k];
-        cd[15] = i2f(mat);
     }
 
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
@@ -681,9 +991,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
 
     free_scene(c);
     int rc;
-    if ((rc = upload_buf(c, &c->d_wide, wide.data(), wide.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_leaves, leaves.data(), leaves.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_hot, hot.data(), hot.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_items, items.data(), items.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_cold, cold.data(), cold.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_mats, mats.data(), mats.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_lights, lights.data(), lights.size() * 4)) != RT_OK) return rc;
@@ -691,9 +999,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if ((rc = upload_buf(c, &c->d_tex, s->textures, s->n_tex_floats * 4)) != RT_OK) return rc;
 
     Scene& sc = c->sc;
-    sc.wide = (const float4*)c->d_wide;
-    sc.leaves = (const int2*)c->d_leaves;
-    sc.tri_hot = (const float4*)c->d_hot;
+    sc.items = (const float4*)c->d_items;
+    sc.n_inner = n_inner;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
@@ -705,7 +1012,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.n_lights = s->n_light_tris;
     sc.n_spheres = s->n_spheres;
     sc.has_root = nn > 0;
-    sc.root_entry = nn > 0 ? entry[0] : 0;
+    sc.root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
     for (int k = 0; k < 3; k++) {
         sc.root_min[k] = nn > 0 ? s->nodes[0].bbox_min[k] : 0.f;
         sc.root_max[k] = nn > 0 ? s->nodes[0].bbox_max[k] : 0.f;
@@ -742,6 +1049,126 @@ int rt_set_sample_count(rt_context* c, int64_t samples) {
     return RT_OK;
 }
 
+namespace {
+
+int ensure_wavefront(rt_context* c, int n_slots) {
+    if (n_slots <= c->wf_slots) {
+        c->wf.n_slots = n_slots;
+        return RT_OK;
+    }
+    if (c->d_wf) (void)hipFree(c->d_wf);
+    c->d_wf = nullptr;
+    c->wf_slots = 0;
+    // st_dir, st_thr, st_col, hits: 16 B each; ray queue: 32 B  => 96 B per slot
+    const size_t bytes = (size_t)n_slots * 96;
+    HIP_TRY(c, hipMalloc(&c->d_wf, bytes));
+    float4* base = (float4*)c->d_wf;
+    c->wf.st_dir = base;
+    c->wf.st_thr = base + (size_t)n_slots;
+    c->wf.st_col = base + 2 * (size_t)n_slots;
+    c->wf.hits = base + 3 * (size_t)n_slots;
+    c->wf.rayq = base + 4 * (size_t)n_slots;
+    c->wf.qcount = c->d_tile_counter + 4;
+    c->wf.cursor = c->d_tile_counter + 6;
+    c->wf.n_slots = n_slots;
+    c->wf_slots = n_slots;
+    return RT_OK;
+}
+
+int trace_grid(rt_context* c, bool stats_kernel) {
+    if (c->trace_occ <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)rt_trace_kernel<false>, 64 * RT_WAVES_PER_BLOCK, 0) != hipSuccess || occ < 1)
+            occ = 4;
+        c->trace_occ = std::min(occ, 8);
+        if (const char* e = getenv("RT_TRACE_OCC")) c->trace_occ = std::max(1, atoi(e));  // experiments only
+    }
+    (void)stats_kernel;
+    return c->num_cus * c->trace_occ;
+}
+
+int render_megakernel(rt_context* c, const Params& P, float* accum, bool want_stats) {
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+    int occ = 0;
+    const void* kfn = want_stats ? (const void*)rt_render_kernel<true> : (const void*)rt_render_kernel<false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * RT_WAVES_PER_BLOCK, 0) != hipSuccess || occ < 1) occ = 2;
+    const int max_blocks = c->num_cus * occ;
+    const int want_blocks = (P.n_tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
+    const int blocks = std::max(1, std::min(max_blocks, want_blocks));
+    if (want_stats)
+        hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
+                           c->d_tile_counter, c->d_stats);
+    else
+        hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
+                           c->d_tile_counter, c->d_stats);
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
+// Wavefront loop: logic -> trace -> logic -> ... until no slot emits a ray.
+int render_wavefront(rt_context* c, const Params& P, float* accum, bool want_stats, bool profile, rt_render_stats* out) {
+    const int n_slots = P.n_tiles * 64;
+    int rc = ensure_wavefront(c, n_slots);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter + 4, 0, 4 * sizeof(unsigned int), c->stream));
+    const long long bound = (long long)P.sample_count * std::max(P.max_bounces, 0) + 2;  // each slot: <= spp*bounces rays
+    const int logic_blocks = (n_slots + RT_LOGIC_BLOCK - 1) / RT_LOGIC_BLOCK;
+    const int tgrid = trace_grid(c, want_stats);
+    const int check_every = 8;
+    size_t ev_used = 0;
+    const size_t ev_cap = 4096;
+    long long it = 0;
+    for (; it < bound; it++) {
+        const int par = (int)(it & 1);
+        if (want_stats)
+            hipLaunchKernelGGL(rt_logic_kernel<true>, dim3(logic_blocks), dim3(RT_LOGIC_BLOCK), 0, c->stream, c->sc, P, c->wf, accum, (int)(it > 0x3fffffff ? 2 + par : it), c->d_stats);
+        else
+            hipLaunchKernelGGL(rt_logic_kernel<false>, dim3(logic_blocks), dim3(RT_LOGIC_BLOCK), 0, c->stream, c->sc, P, c->wf, accum, (int)(it > 0x3fffffff ? 2 + par : it), c->d_stats);
+        const bool timed = profile && ev_used + 2 <= ev_cap;
+        if (timed) {
+            while (c->ev_pool.size() < ev_used + 2) {
+                hipEvent_t e;
+                HIP_TRY(c, hipEventCreate(&e));
+                c->ev_pool.push_back(e);
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used], c->stream));
+        }
+        if (want_stats)
+            hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tgrid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, c->wf.rayq, c->wf.qcount + par,
+                               c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats);
+        else
+            hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tgrid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, c->wf.rayq, c->wf.qcount + par,
+                               c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats);
+        if (timed) {
+            HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
+            ev_used += 2;
+        }
+        if ((it + 1) % check_every == 0) {  // has the pipeline drained?
+            HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->wf.qcount + par, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->h_pinned[0] == 0) { it++; break; }
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (out) {
+        out->iterations = (uint32_t)it;
+        if (profile && ev_used) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            double sum = 0.0;
+            for (size_t i = 0; i + 1 < ev_used; i += 2) {
+                float ms = 0.f;
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
+                sum += ms;
+            }
+            out->trace_ms = sum;
+            out->trace_launches = (uint32_t)(ev_used / 2);
+        }
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
 int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) {
     if (!c) return RT_ERR_INVALID;
     if (!c->has_scene) return set_err(c, RT_ERR_NO_SCENE, "rt_render before rt_upload_scene");
@@ -768,31 +1195,21 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
         c->samples_done = 0;
     }
     const bool want_stats = (P.flags & RT_F_STATS) != 0;
-    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+    const bool profile = (P.flags & RT_F_PROFILE) != 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
     if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
-    if (P.n_tiles > 0 && P.sample_count > 0) {
-        // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more than the work
-        int occ = 0;
-        const void* kfn = want_stats ? (const void*)rt_render_kernel<true> : (const void*)rt_render_kernel<false>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * RT_WAVES_PER_BLOCK, 0) != hipSuccess || occ < 1) occ = 2;
-        const int max_blocks = c->num_cus * occ;
-        const int want_blocks = (P.n_tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
-        const int blocks = std::max(1, std::min(max_blocks, want_blocks));
+    const bool work = P.n_tiles > 0 && P.sample_count > 0;
+    if (work) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (want_stats)
-            hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
-                               c->d_tile_counter, c->d_stats);
-        else
-            hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
-                               c->d_tile_counter, c->d_stats);
-        HIP_TRY(c, hipGetLastError());
+        if (P.flags & RT_F_MEGAKERNEL) rc = render_megakernel(c, P, accum, want_stats);
+        else rc = render_wavefront(c, P, accum, want_stats, profile, stats);
+        if (rc != RT_OK) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->samples_done += P.sample_count;
     if (stats) {
-        memset(stats, 0, sizeof(*stats));
-        if (P.n_tiles > 0 && P.sample_count > 0) {
+        if (work) {
             float ms = 0.f;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
             stats->kernel_ms = ms;
@@ -864,19 +1281,31 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     if (!c->has_scene) return set_err(c, RT_ERR_NO_SCENE, "rt_trace_rays before rt_upload_scene");
     if (n == 0) return RT_OK;
     if (!org_dir) return set_err(c, RT_ERR_INVALID, "null rays");
+    if (n > 0x7fffffffu / 8) return set_err(c, RT_ERR_INVALID, "too many rays in one call");
     HIP_TRY(c, hipSetDevice(c->device));
     DevTmp tmp;
     float* d_rays = (float*)tmp.get(n * 6 * 4);
+    float4* d_q = (float4*)tmp.get(n * 32);
+    float4* d_hits = (float4*)tmp.get(n * 16);
     int* d_prim = (int*)tmp.get(n * 4);
     float* d_t = (float*)tmp.get(n * 4);
     float* d_pos = (float*)tmp.get(n * 12);
     float* d_nrm = (float*)tmp.get(n * 12);
     int* d_cnt = (int*)tmp.get(n * 12);
-    if (!d_rays || !d_prim || !d_t || !d_pos || !d_nrm || !d_cnt) return set_err(c, RT_ERR_NOMEM, "device scratch allocation failed");
+    if (!d_rays || !d_q || !d_hits || !d_prim || !d_t || !d_pos || !d_nrm || !d_cnt)
+        return set_err(c, RT_ERR_NOMEM, "device scratch allocation failed");
     HIP_TRY(c, hipMemcpyAsync(d_rays, org_dir, n * 24, hipMemcpyHostToDevice, c->stream));
-    const int bs = 64 * RT_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(rt_trace_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, c->stream, c->sc, d_rays, n, flags, d_prim,
-                       d_t, d_pos, d_nrm, d_cnt);
+    hipLaunchKernelGGL(rt_fill_queue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_rays, n, d_q);
+    unsigned int* d_n = c->d_tile_counter + 8;  // [8] = ray count, [9] = cursor
+    const unsigned int hn[2] = {(unsigned int)n, 0u};
+    HIP_TRY(c, hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, n * 12, c->stream));
+    const int grid = std::max(1, std::min(trace_grid(c, true), (int)((n + 255) / 256)));
+    // the same persistent kernel the renderer uses (with refill), restricted to closest hit (+ spheres if asked)
+    hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(grid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,
+                       flags, d_cnt, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(rt_hitinfo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays, d_hits, n, d_prim,
+                       d_t, d_pos, d_nrm);
     HIP_TRY(c, hipGetLastError());
     if (prim_id) HIP_TRY(c, hipMemcpyAsync(prim_id, d_prim, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (t) HIP_TRY(c, hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, c->stream));

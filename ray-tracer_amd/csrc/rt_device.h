@@ -18,32 +18,38 @@ namespace rtd {
 
 // ------------------------------------------------------------------ layouts in HBM
 //
-// wide node  (64 B = 4 x float4, one per INNER node of the reference BVH; both child
-//             boxes + both child entries in one record, so one inner visit = one 64-B
-//             fetch instead of the reference's two 40-B child fetches, main.cu:268-269):
+// ITEM STREAM (64 B = 4 x float4 per item): inner nodes and triangles live in ONE array so that a
+// wave advances every lane by one traversal step -- an inner-node visit or one triangle test --
+// with the same four 16-byte loads (the vector-memory pipeline, not the VALU, is what bounds
+// this kernel: its cost is per wave-instruction, so every load must serve as many lanes as
+// possible).  Items [0, n_inner) are the INNER nodes of the reference BVH in its BFS order,
+// items [n_inner, n_inner + n_tris) the triangles in the reference's (leaf-contiguous) order.
+//   inner item: both child boxes + both child entries (one 64-B fetch per inner visit instead
+//               of the reference's two 40-B child fetches, main.cu:268-269)
 //     q0 = (A.min.x, A.min.y, A.min.z, A.max.x)
 //     q1 = (A.max.y, A.max.z, B.min.x, B.min.y)
 //     q2 = (B.min.z, B.max.x, B.max.y, B.max.z)
-//     q3 = (entryA, entryB, refNodeId, 0)           as int bits
-//   entry >= 0 : index of an inner node in `wide`;  entry < 0 : ~entry = index in `leaves`
-// leaf       (8 B int2): (first triangle id, triangle count)   [main.cu:247-248]
-// tri hot    (48 B = 3 x float4): v0, e1 = v1 - v0, e2 = v2 - v0 (the single subtraction
-//             of main.cu:43-44 done at upload, bit-identical), w = (.., .., matId)
-//     h0 = (v0.x, v0.y, v0.z, e1.x)  h1 = (e1.y, e1.z, e2.x, e2.y)  h2 = (e2.z, 0, 0, matId bits)
+//     q3 = (entryA, entryB, refNodeId, 0)            as int bits
+//     entry = item index of the child (inner node, or FIRST triangle of a leaf child),
+//             RT_TRAV_EMPTY for a leaf without triangles
+//   triangle item: v0, e1 = v1 - v0, e2 = v2 - v0 (the single subtraction of main.cu:43-44 done
+//               at upload, bit-identical)
+//     q0 = (v0.x, v0.y, v0.z, e1.x)  q1 = (e1.y, e1.z, e2.x, e2.y)
+//     q2 = (e2.z, flags, matId, 0)   flags bit0 = last triangle of its leaf, bit1 = first
+//     q3 = unused
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
 // light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
-    const float4* wide;
-    const int2* leaves;
-    const float4* tri_hot;
+    const float4* items;
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
     const float4* spheres;
     const float* tex;
     long long n_tex;
+    int n_inner;
     int n_tris;
     int n_mats;
     int n_lights;
@@ -306,65 +312,121 @@ struct Attractor {
 // pushed and popped again (same order, half the LDS traffic).
 //
 // stk: this lane's column of the wave's LDS stack; entry i lives at stk[i * 64].
+#define RT_TRAV_DONE (-1)   // query finished
+#define RT_TRAV_EMPTY (-2)  // a leaf without triangles (visited, nothing to test)
+
+// Per-lane traversal state of one closest-hit query.
+struct Trav {
+    f3 o, d, inv;
+    int cur;      // item to visit next (inner node or triangle), RT_TRAV_EMPTY, or RT_TRAV_DONE
+    int sp;       // entries on this lane's LDS stack
+    int hitTri;   // triangle id (hitTriIndex / 25) or -1
+    float minD2;  // minDistSqr, main.cu:223
+    f3 hitPos;
+};
+
+// main.cu:221-236: reset the query and test the root box once.
+__device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d) {
+    t.o = o;
+    t.d = d;
+    t.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    t.sp = 0;
+    t.hitTri = -1;
+    t.minD2 = 1e12f;
+    t.hitPos = mk(0.f, 0.f, 0.f);
+    // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
+    // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
+    t.cur = (sc.has_root && aabb_distance(o, t.inv, ld3(sc.root_min), ld3(sc.root_max)) <= 1e12f) ? sc.root_entry : RT_TRAV_DONE;
+}
+
+__device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
+    if (t.sp > 0) { t.sp--; t.cur = stk[t.sp * 64]; }
+    else t.cur = RT_TRAV_DONE;
+}
+
+// ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit
+// (main.cu:265-279) or one triangle test of the current leaf (main.cu:249-264).  All lanes of
+// the wave share the four item loads, whatever kind of item each of them holds.
+template <bool STATS>
+__device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn) {
+    if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
+        if (STATS) cn.leaf++;
+        trav_pop(t, stk);
+        return;
+    }
+    const float4* w = sc.items + 4 * (size_t)t.cur;
+    const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+    if (t.cur < sc.n_inner) {
+        if (STATS) cn.inner++;
+        float dA = aabb_distance(t.o, t.inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+        float dB = aabb_distance(t.o, t.inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+        dA = dA * dA;
+        dB = dB * dB;
+        const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
+        const bool aNear = dA < dB;
+        const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
+        const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
+        if (dFar < t.minD2) { stk[t.sp * 64] = eFar; t.sp++; }
+        if (dNear < t.minD2) t.cur = eNear;
+        else trav_pop(t, stk);
+    } else {
+        const int flags = __float_as_int(q2.y);
+        if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
+        f3 pos;
+        if (ray_triangle(t.o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), pos)) {
+            const float nd = len2(pos - t.o);
+            if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = t.cur - sc.n_inner; }
+        }
+        if (flags & 1) trav_pop(t, stk);
+        else t.cur++;
+    }
+}
+
+// ENABLE_BVH false, main.cu:285-301
+template <bool STATS>
+__device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Counters& cn) {
+    for (int i = 0; i < sc.n_tris; i++) {
+        const float4* h = sc.items + 4 * ((size_t)sc.n_inner + i);
+        const float4 h0 = h[0], h1 = h[1], h2 = h[2];
+        if (STATS) cn.tri++;
+        f3 pos;
+        if (ray_triangle(t.o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
+            const float nd = len2(pos - t.o);
+            if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = i; }
+        }
+    }
+    t.cur = RT_TRAV_DONE;
+}
+
+// Analytic spheres after the triangles, main.cu:305-334.  Returns the sphere index or -1.
+__device__ __forceinline__ int trav_spheres(const Scene& sc, Trav& t, f3& sPos) {
+    int hitSphere = -1;
+    for (int i = 0; i < sc.n_spheres; i++) {
+        const float4 s0 = sc.spheres[2 * i];
+        f3 hp, hn;
+        if (intersect_sphere(t.o, t.d, mk(s0.x, s0.y, s0.z), s0.w, hp, hn)) {
+            const float d2 = len2(hp - t.o);
+            if (d2 >= t.minD2) continue;
+            t.minD2 = d2;
+            sPos = hp;
+            hitSphere = i;
+        }
+    }
+    return hitSphere;
+}
+
+// Whole query for one lane (megakernel mode): steps until done.
 template <bool STATS>
 __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool use_bvh, int* stk, int& hitTri,
                                               float& minD2, f3& hitPos, Counters& cn) {
-    hitTri = -1;
-    minD2 = 1e12f;
+    Trav t;
     if (STATS) cn.rays++;
-    if (!use_bvh) {  // main.cu:285-301
-        for (int i = 0; i < sc.n_tris; i++) {
-            const float4 h0 = sc.tri_hot[3 * (size_t)i], h1 = sc.tri_hot[3 * (size_t)i + 1], h2 = sc.tri_hot[3 * (size_t)i + 2];
-            if (STATS) cn.tri++;
-            f3 pos;
-            if (ray_triangle(o, d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
-                const float nd = len2(pos - o);
-                if (nd < minD2) { minD2 = nd; hitPos = pos; hitTri = i; }
-            }
-        }
-        return;
-    }
-    if (!sc.has_root) return;
-    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
-    // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
-    if (!(aabb_distance(o, inv, ld3(sc.root_min), ld3(sc.root_max)) <= 1e12f)) return;
-    int sp = 0;
-    int cur = sc.root_entry;
-    for (;;) {
-        if (cur >= 0) {
-            if (STATS) cn.inner++;
-            const float4* w = sc.wide + 4 * (size_t)cur;
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-            float dA = aabb_distance(o, inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-            float dB = aabb_distance(o, inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
-            dA = dA * dA;
-            dB = dB * dB;
-            const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
-            const bool aNear = dA < dB;
-            const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
-            const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
-            if (dFar < minD2) { stk[sp * 64] = eFar; sp++; }
-            if (dNear < minD2) { cur = eNear; continue; }
-        } else {
-            if (STATS) cn.leaf++;
-            const int2 lf = sc.leaves[~cur];
-            const int end = lf.x + lf.y;
-            for (int i = lf.x; i < end; i++) {
-                const float4* t = sc.tri_hot + 3 * (size_t)i;
-                const float4 h0 = t[0], h1 = t[1], h2 = t[2];
-                if (STATS) cn.tri++;
-                f3 pos;
-                if (ray_triangle(o, d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
-                    const float nd = len2(pos - o);
-                    if (nd < minD2) { minD2 = nd; hitPos = pos; hitTri = i; }
-                }
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * 64];
-    }
+    trav_begin(sc, t, o, d);
+    if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
+    while (t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn);
+    hitTri = t.hitTri;
+    minD2 = t.minD2;
+    hitPos = t.hitPos;
 }
 
 // ------------------------------------------------------------------ shading (material.h)
@@ -427,7 +489,7 @@ struct HitFrame {
 };
 
 __device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int tri, f3 hitPos) {  // material.h:44-62
-    const float4* t = sc.tri_hot + 3 * (size_t)tri;
+    const float4* t = sc.items + 4 * ((size_t)sc.n_inner + tri);
     const float4 h0 = t[0], h1 = t[1], h2 = t[2];
     const float4* c = sc.tri_cold + 4 * (size_t)tri;
     const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
