@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--bounces", type=int, default=6)
     ap.add_argument("--partition", choices=["samples", "rows"], default="samples")
-    ap.add_argument("--mode", choices=["wavefront", "megakernel"], default="wavefront")
+    ap.add_argument("--mode", choices=["wavefront", "megakernel"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=0, help="use the synthetic instanced field instead of --scene")
@@ -86,8 +86,7 @@ def main():
     r = rt.Renderer(local_rank)
     r.upload(scene)
     p = rt.default_params(scene.camera, spp=spp, width=W, height=H, max_bounces=args.bounces)
-    if args.mode == "megakernel":
-        p.flags |= rt.F_MEGAKERNEL
+    p.flags |= rt.F_MEGAKERNEL if args.mode == "megakernel" else rt.F_WAVEFRONT
     if world > 1:
         D.partition_params(p, rank, world, args.partition, spp)
     rows = rt.band_rows_of(p)

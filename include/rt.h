@@ -116,7 +116,9 @@ enum {
     RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9  (reserved, rejected) */
     RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14 (reserved, rejected) */
     RT_F_STATS = 1 << 8,        /* count rays / node visits / triangle tests */
-    RT_F_MEGAKERNEL = 1 << 9,   /* one fused persistent kernel (lane = pixel) instead of the wavefront pipeline */
+    RT_F_MEGAKERNEL = 1 << 9,   /* force the fused persistent kernel (lane = pixel) */
+    RT_F_WAVEFRONT = 1 << 11,   /* force the wavefront pipeline (logic kernel + persistent trace kernel);
+                                   with neither bit the library picks (currently the fused kernel) */
     RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every trace-kernel launch (rt_render_stats.trace_ms) */
     RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
 };

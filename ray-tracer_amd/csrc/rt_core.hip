@@ -356,18 +356,27 @@ __global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Para
 
 // Persistent closest-hit kernel.  queue: n rays (2 x float4 each); results go to hits[slot].
 // counts (optional): per-slot {inner, leaf, tri} visit counts for the rt_trace_rays test hook.
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 16  // waves per trace block: they share one LDS copy of the top of the tree
+#endif
+// dynamic LDS (rt_lds, declared in rt_device.h): [4 * n_cached node pieces][RT_TRACE_WAVES x stack_entries x 64 ints]
+
 template <bool STATS>
-__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_trace_kernel(Scene sc, const float4* __restrict__ rayq,
-                                                                             const unsigned int* __restrict__ n_rays_ptr,
-                                                                             unsigned int* __restrict__ cursor,
-                                                                             float4* __restrict__ hits, unsigned flags,
-                                                                             int* __restrict__ counts,
-                                                                             unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[RT_WAVES_PER_BLOCK][RT_STACK_ENTRIES][64];
+__global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc, const float4* __restrict__ rayq,
+                                                                        const unsigned int* __restrict__ n_rays_ptr,
+                                                                        unsigned int* __restrict__ cursor,
+                                                                        float4* __restrict__ hits, unsigned flags,
+                                                                        int* __restrict__ counts,
+                                                                        unsigned long long* __restrict__ stats, int n_cached,
+                                                                        int stack_entries) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    int* stk = &lds_stack[wave][0][lane];
     const unsigned int n_rays = *n_rays_ptr;
+    if ((unsigned long long)blockIdx.x * RT_TRACE_WAVES * 64 >= n_rays) return;  // no wave of this block has a first chunk
+    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_TRACE_WAVES)  // item i>>2, piece i&3 (coalesced read)
+        rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
+    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+    __syncthreads();
     const bool use_bvh = (flags & RT_F_BVH) != 0;
     const bool spheres_on = (flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
     Counters cn, tot;
@@ -381,8 +390,8 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_trace_kernel(Scene
     // further chunks come from ONE shared cursor (a same-address atomic costs ~12 ns serialised,
     // so chunks are large when the queue is long).  Waves whose first chunk lies beyond the queue
     // leave at once.
-    const unsigned int n_waves = gridDim.x * RT_WAVES_PER_BLOCK;
-    const unsigned int gw = blockIdx.x * RT_WAVES_PER_BLOCK + wave;
+    const unsigned int n_waves = gridDim.x * RT_TRACE_WAVES;
+    const unsigned int gw = blockIdx.x * RT_TRACE_WAVES + wave;
 #ifndef RT_DIST
 #define RT_DIST 0
 #endif
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK) void rt_trace_kernel(Scene
             }
         }
         if (!__any(has)) break;  // nothing in flight: the queue is exhausted as well
-        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn);
+        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn, n_cached);
         if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
             int tri = t.hitTri;
             if (spheres_on) {
@@ -671,7 +680,7 @@ struct rt_context {
     Wavefront wf{};
     void* d_wf = nullptr;
     int wf_slots = 0;
-    int trace_occ = 0;       // resident trace blocks per CU
+    int trace_lds_set = 0;   // dynamic-LDS limit already granted to the trace kernels
     std::vector<hipEvent_t> ev_pool;
     unsigned int* h_pinned = nullptr;
 };
@@ -1075,16 +1084,32 @@ int ensure_wavefront(rt_context* c, int n_slots) {
     return RT_OK;
 }
 
-int trace_grid(rt_context* c, bool stats_kernel) {
-    if (c->trace_occ <= 0) {
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)rt_trace_kernel<false>, 64 * RT_WAVES_PER_BLOCK, 0) != hipSuccess || occ < 1)
-            occ = 4;
-        c->trace_occ = std::min(occ, 8);
-        if (const char* e = getenv("RT_TRACE_OCC")) c->trace_occ = std::max(1, atoi(e));  // experiments only
-    }
-    (void)stats_kernel;
-    return c->num_cus * c->trace_occ;
+// Launch shape of the trace kernel for the uploaded scene: one 1024-thread block per CU whose LDS
+// (160 KiB) holds the per-lane stacks (bvh depth entries) and as much of the top of the tree as fits.
+struct TraceCfg {
+    int grid, n_cached, stack_entries;
+    size_t lds_bytes;
+};
+
+TraceCfg trace_cfg(rt_context* c) {
+    TraceCfg t;
+    t.stack_entries = std::max(c->bvh_depth, 1);
+    const size_t stack_bytes = (size_t)RT_TRACE_WAVES * t.stack_entries * 64 * sizeof(int);
+    const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
+    size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / 64 : 0;
+    if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
+    t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)c->sc.n_inner);
+    t.lds_bytes = (size_t)t.n_cached * 64 + stack_bytes;
+    t.grid = c->num_cus;
+    return t;
+}
+
+int set_trace_lds(rt_context* c, const TraceCfg& t) {
+    if ((size_t)c->trace_lds_set >= t.lds_bytes) return RT_OK;
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_trace_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_trace_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    c->trace_lds_set = (int)t.lds_bytes;
+    return RT_OK;
 }
 
 int render_megakernel(rt_context* c, const Params& P, float* accum, bool want_stats) {
@@ -1113,7 +1138,8 @@ int render_wavefront(rt_context* c, const Params& P, float* accum, bool want_sta
     HIP_TRY(c, hipMemsetAsync(c->d_tile_counter + 4, 0, 4 * sizeof(unsigned int), c->stream));
     const long long bound = (long long)P.sample_count * std::max(P.max_bounces, 0) + 2;  // each slot: <= spp*bounces rays
     const int logic_blocks = (n_slots + RT_LOGIC_BLOCK - 1) / RT_LOGIC_BLOCK;
-    const int tgrid = trace_grid(c, want_stats);
+    const TraceCfg tc = trace_cfg(c);
+    if ((rc = set_trace_lds(c, tc)) != RT_OK) return rc;
     const int check_every = 8;
     size_t ev_used = 0;
     const size_t ev_cap = 4096;
@@ -1134,11 +1160,11 @@ int render_wavefront(rt_context* c, const Params& P, float* accum, bool want_sta
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used], c->stream));
         }
         if (want_stats)
-            hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tgrid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, c->wf.rayq, c->wf.qcount + par,
-                               c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats);
+            hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, c->wf.rayq,
+                               c->wf.qcount + par, c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats, tc.n_cached, tc.stack_entries);
         else
-            hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tgrid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, c->wf.rayq, c->wf.qcount + par,
-                               c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats);
+            hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, c->wf.rayq,
+                               c->wf.qcount + par, c->wf.cursor + par, c->wf.hits, P.flags, (int*)nullptr, c->d_stats, tc.n_cached, tc.stack_entries);
         if (timed) {
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
             ev_used += 2;
@@ -1201,7 +1227,7 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
     const bool work = P.n_tiles > 0 && P.sample_count > 0;
     if (work) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (P.flags & RT_F_MEGAKERNEL) rc = render_megakernel(c, P, accum, want_stats);
+        if (!(P.flags & RT_F_WAVEFRONT)) rc = render_megakernel(c, P, accum, want_stats);
         else rc = render_wavefront(c, P, accum, want_stats, profile, stats);
         if (rc != RT_OK) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1300,10 +1326,12 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     const unsigned int hn[2] = {(unsigned int)n, 0u};
     HIP_TRY(c, hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_cnt, 0, n * 12, c->stream));
-    const int grid = std::max(1, std::min(trace_grid(c, true), (int)((n + 255) / 256)));
+    const TraceCfg tc = trace_cfg(c);
+    int rc = set_trace_lds(c, tc);
+    if (rc != RT_OK) return rc;
     // the same persistent kernel the renderer uses (with refill), restricted to closest hit (+ spheres if asked)
-    hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(grid), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,
-                       flags, d_cnt, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,
+                       flags, d_cnt, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
     hipLaunchKernelGGL(rt_hitinfo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays, d_hits, n, d_prim,
                        d_t, d_pos, d_nrm);
     HIP_TRY(c, hipGetLastError());

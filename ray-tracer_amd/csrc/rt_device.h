@@ -312,6 +312,8 @@ struct Attractor {
 // pushed and popped again (same order, half the LDS traffic).
 //
 // stk: this lane's column of the wave's LDS stack; entry i lives at stk[i * 64].
+extern __shared__ float4 rt_lds[];  // dynamic LDS: [4 * n_cached node pieces][per-lane stacks]
+
 #define RT_TRAV_DONE (-1)   // query finished
 #define RT_TRAV_EMPTY (-2)  // a leaf without triangles (visited, nothing to test)
 
@@ -347,15 +349,27 @@ __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
 // ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit
 // (main.cu:265-279) or one triangle test of the current leaf (main.cu:249-264).  All lanes of
 // the wave share the four item loads, whatever kind of item each of them holds.
+//
+// n_cached: the first n_cached inner items (the top of the tree in BFS order) are held in the
+// dynamic LDS array as four piece arrays rt_lds[k * n_cached + node]: a divergent 16-byte request costs the
+// vector-memory pipeline a full cycle each, the LDS serves them several times faster.
 template <bool STATS>
-__device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn) {
+__device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached = 0) {
     if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
         if (STATS) cn.leaf++;
         trav_pop(t, stk);
         return;
     }
-    const float4* w = sc.items + 4 * (size_t)t.cur;
-    const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+    float4 q0, q1, q2, q3;
+    if (t.cur < n_cached) {
+        q0 = rt_lds[t.cur];
+        q1 = rt_lds[n_cached + t.cur];
+        q2 = rt_lds[2 * n_cached + t.cur];
+        q3 = rt_lds[3 * n_cached + t.cur];
+    } else {
+        const float4* w = sc.items + 4 * (size_t)t.cur;
+        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
+    }
     if (t.cur < sc.n_inner) {
         if (STATS) cn.inner++;
         float dA = aabb_distance(t.o, t.inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));

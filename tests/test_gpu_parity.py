@@ -93,7 +93,7 @@ def image_metrics(a, b):
 ])
 def test_image_matches_oracle_same_rng(ob, rt, gpu, scenes, name, size, spp, bounces, mode):
     sc = scenes(name)
-    flags = rt.F_DEFAULT | rt.F_STATS | (rt.F_MEGAKERNEL if mode == "megakernel" else 0)
+    flags = rt.F_DEFAULT | rt.F_STATS | (rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT)
     p = rt.default_params(sc.camera, spp=spp, width=size, height=size, max_bounces=bounces, flags=flags)
     gpu.upload(sc)
     gpu.reset()
