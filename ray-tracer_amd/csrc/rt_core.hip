@@ -69,14 +69,18 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK, RT_MIN_WAVES) void rt_rend
         const uint32_t pixel = (uint32_t)(x + y * P.width);  // main.cu:171
 
         f3 color = mk(0.f, 0.f, 0.f);
-        int k = 0;                                  // samples started
         const int spp = in_image ? P.sample_count : 0;
+        int k = 0;                                  // samples started
         bool alive = false;
         int bounce = 0;
         PathState ray;
         Rng rng;
         rng.init(P.seed, pixel, 0);
 
+        if (P.max_bounces <= 0) {  // the bounce loop never runs: every sample contributes 0
+            if (STATS) cn.paths += spp;
+            k = spp;
+        }
         for (;;) {
             if (!alive && k < spp) {  // regenerate: camera sample k (main.cu:178-217)
                 rng.init(P.seed, pixel, (uint32_t)(P.sample_begin + k));

@@ -1,0 +1,373 @@
+"""GPU parity of the device primitives, the shading entry, the committed golden fixtures and the error
+behaviour of the C-ABI.  Everything goes through librt_amd.so; the oracle is only the checker."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rnd(n, k, seed, scale=2.0):
+    return (np.random.default_rng(seed).normal(size=(n, k)) * scale).astype(np.float32)
+
+
+def unit(v):
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+# ---- integer / pure IEEE arithmetic ops: bit-exact ---------------------------------------------------------
+
+def test_rng_bit_exact(ob, rt, gpu):
+    rng = np.random.default_rng(1)
+    rec = rng.integers(0, 2 ** 32, size=(4096, 4), dtype=np.uint64).astype(np.uint32)
+    assert same_bits(gpu.debug_op(rt.OP_RNG, rec), ob.debug_op(rt.OP_RNG, rec))
+
+
+def test_portable_math_bit_exact(ob, rt, gpu):
+    rng = np.random.default_rng(2)
+    n = 20000
+    for fn, x, y in [(0, rng.uniform(-20, 20, n), None), (0, rng.uniform(0, 6.3, n), None), (1, rng.uniform(-1, 1, n), None),
+                     (2, rng.uniform(-1, 1, n), None), (3, rng.normal(size=n), rng.normal(size=n)),
+                     (4, (rng.integers(0, 1 << 24, n) + 1) / 16777216.0, None)]:
+        rec = np.zeros((n, 3), np.float32)
+        rec[:, 0] = np.full(n, fn, np.int32).view(np.float32)
+        rec[:, 1] = x
+        if y is not None:
+            rec[:, 2] = y
+        assert same_bits(gpu.debug_op(rt.OP_PMATH, rec), ob.debug_op(rt.OP_PMATH, rec)), fn
+
+
+def test_triangle_and_box_tests_bit_exact(ob, rt, gpu):
+    n = 50000
+    rec = np.concatenate([rnd(n, 3, 3), unit(rnd(n, 3, 4)), rnd(n, 9, 5)], 1)
+    g, o = gpu.debug_op(rt.OP_TRI_INTERSECT, rec), ob.debug_op(rt.OP_TRI_INTERSECT, rec)
+    assert np.array_equal(g[:, 0], o[:, 0]) and 0.03 < o[:, 0].mean() < 0.5
+    hit = o[:, 0] == 1
+    assert same_bits(g[hit], o[hit])
+    d = unit(rnd(n, 3, 6))
+    d[::7, 0] = 0.0          # zero direction components: inf / NaN slabs
+    d[::11, 1] = 0.0
+    c = rnd(n, 3, 7)
+    h = np.abs(rnd(n, 3, 8, 1.0))
+    rec = np.concatenate([rnd(n, 3, 9), d, c - h, c + h], 1)
+    rec[::13, 0] = rec[::13, 6]   # origins exactly on a face
+    assert same_bits(gpu.debug_op(rt.OP_AABB_DIST, rec), ob.debug_op(rt.OP_AABB_DIST, rec))
+
+
+def test_sphere_floor_bit_exact(ob, rt, gpu):
+    n = 20000
+    rec = np.concatenate([rnd(n, 3, 10), unit(rnd(n, 3, 11)), rnd(n, 3, 12), np.abs(rnd(n, 1, 13, 1.0)) + 0.1], 1)
+    g, o = gpu.debug_op(rt.OP_SPHERE, rec), ob.debug_op(rt.OP_SPHERE, rec)
+    assert np.array_equal(g[:, 0], o[:, 0]) and same_bits(g[o[:, 0] == 1], o[o[:, 0] == 1])
+    rec = np.concatenate([rnd(n, 3, 14), unit(rnd(n, 3, 15)), rnd(n, 1, 16)], 1)
+    g, o = gpu.debug_op(rt.OP_FLOOR, rec), ob.debug_op(rt.OP_FLOOR, rec)
+    assert np.array_equal(g[:, 0], o[:, 0]) and same_bits(g[o[:, 0] == 1], o[o[:, 0] == 1])
+
+
+def test_light_sampling_primitives_bit_exact(ob, rt, gpu):
+    n = 20000
+    tri = rnd(n, 9, 20)
+    rec = np.concatenate([rnd(n, 3, 21), unit(rnd(n, 3, 22)), tri], 1)
+    assert same_bits(gpu.debug_op(rt.OP_ITRI_PDF, rec), ob.debug_op(rt.OP_ITRI_PDF, rec))
+    r12 = np.random.default_rng(23).uniform(0, 1, (n, 2)).astype(np.float32)
+    rec = np.concatenate([rnd(n, 3, 24), r12, tri], 1)
+    gs, os_ = gpu.debug_op(rt.OP_ITRI_SAMPLE, rec), ob.debug_op(rt.OP_ITRI_SAMPLE, rec)
+    assert same_bits(gs, os_)
+    # a sampled direction hits its triangle: pdf through the GPU is positive and equals the oracle's
+    rec2 = np.concatenate([rec[:, 0:3], gs, tri], 1)
+    gp = gpu.debug_op(rt.OP_ITRI_PDF, rec2)
+    assert same_bits(gp, ob.debug_op(rt.OP_ITRI_PDF, rec2)) and (gp > 0).mean() > 0.95
+    quad = np.concatenate([rnd(n, 3, 25), rnd(n, 3, 26), rnd(n, 3, 27)], 1)
+    rec = np.concatenate([rnd(n, 3, 28), unit(rnd(n, 3, 29)), quad], 1)
+    assert same_bits(gpu.debug_op(rt.OP_ATTRACTOR_PDF, rec), ob.debug_op(rt.OP_ATTRACTOR_PDF, rec))
+    rec = np.concatenate([rnd(n, 3, 30), r12, quad], 1)
+    assert same_bits(gpu.debug_op(rt.OP_ATTRACTOR_SAMPLE, rec), ob.debug_op(rt.OP_ATTRACTOR_SAMPLE, rec))
+
+
+def test_env_index_and_camera_rays_bit_exact(ob, rt, gpu, scenes):
+    n = 20000
+    d = unit(rnd(n, 3, 31))
+    rec = np.concatenate([d, np.full((n, 1), 1024, np.float32), np.full((n, 1), 512, np.float32)], 1)
+    assert same_bits(gpu.debug_op(rt.OP_ENV_INDEX, rec), ob.debug_op(rt.OP_ENV_INDEX, rec))
+    sc = scenes("scene.txt")
+    rng = np.random.default_rng(32)
+    rec = np.stack([rng.integers(0, 1920, n), rng.integers(0, 1080, n), rng.integers(0, 4096, n)], 1).astype(np.uint32)
+    for variant in range(3):
+        p = rt.default_params(sc.camera, spp=1, width=1920, height=1080)
+        if variant >= 1:
+            p.cam.aperture = 0.15            # thin lens
+            p.cam.rot[:] = [0.2, -0.4, 0.1]
+        if variant == 2:
+            p.cam.ang_vel[:] = [0.05, 0.1, -0.02]   # motion blur: per-sample rotation matrix on the device
+            p.cam.vel[:] = [0.3, 0.0, -0.2]
+        assert same_bits(gpu.debug_op(rt.OP_CAMERA_RAY, rec, p), ob.debug_op(rt.OP_CAMERA_RAY, rec, p)), variant
+
+
+def test_tonemap_within_libm_tolerance(ob, rt, gpu):
+    x = np.abs(rnd(20000, 3, 33, 1.5))
+    g, o = gpu.debug_op(rt.OP_TONEMAP, x), ob.debug_op(rt.OP_TONEMAP, x)
+    assert np.allclose(g, o, rtol=2e-6, atol=1e-7)       # powf: device libm vs glibc, a few ulp
+
+
+# ---- Material::reflect on real hits --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["scene_cornellbox.txt", "scene.txt", "scene2_is.txt"])
+def test_shade_hits_bit_exact(ob, rt, gpu, scenes, name):
+    sc = scenes(name)
+    g = np.load(os.path.join(GOLD, name.replace(".txt", ".npz")))
+    rays, prim = g["rays"], g["prim"]
+    hit = prim >= 0
+    prim_o, t, pos, nrm, _ = ob.trace_rays(sc, rays[hit])
+    n = int(hit.sum())
+    rec = np.zeros((n, 16), np.float32)
+    rec[:, 0:3] = rays[hit, 0:3]
+    rec[:, 3:6] = rays[hit, 3:6]
+    rec[:, 6:9] = np.random.default_rng(5).uniform(0.2, 1.0, (n, 3))
+    rec[:, 9] = 1.0
+    rec[:, 10:13] = pos
+    rec[:, 13] = prim_o.astype(np.int32).view(np.float32)
+    rec[:, 14] = np.arange(n, dtype=np.uint32).view(np.float32)
+    rec[:, 15] = (np.arange(n, dtype=np.uint32) % 7).view(np.float32)
+    gpu.upload(sc)
+    a, b = gpu.shade_hits(rec, 37811), ob.shade_hits(sc, rec, 37811)
+    assert same_bits(a, b)
+    mats = np.array([m.type for m in sc.materials()])
+    used = set(mats[sc.tris()[prim_o, 24].astype(int)])
+    assert len(used) >= 1
+
+
+def test_shade_every_material_type_bit_exact(ob, rt, gpu):
+    """One big triangle per material type 0..6 (+ an unknown type), textured Lambert included."""
+    tex = np.random.default_rng(9).uniform(0, 1, (16, 16, 3)).astype(np.float32)
+    mats = []
+    for ty in [0, 1, 2, 3, 4, 5, 6, 9]:
+        m = rt.Material(); m.type = ty; m.color = 0x80C040; m.p1 = 0.4; m.p2 = 0.2
+        m.image_offset[:] = [-1, -1, -1]
+        if ty == 3:
+            m.image_offset[0] = 0; m.image_width = 16; m.image_height = 16
+        mats.append(m)
+    recs = np.zeros((len(mats) + 1, 25), np.float32)
+    for i in range(len(mats) + 1):
+        z = -2.0 - i
+        recs[i, 0:9] = [-5, -5, z, 5, -5, z, 0, 5, z]
+        recs[i, 9:18] = [0.1, 0.0, 1.0, -0.1, 0.1, 1.0, 0.0, -0.1, 1.0]
+        recs[i, 18:24] = [0, 0, 0.9, 0, 0.5, 0.9]
+        recs[i, 24] = min(i, len(mats) - 1) + 0.001
+    recs[-1, 24] = 5 + 1000 + 0.001      # an importance-sampled light of material 5
+    sc = rt.Scene.from_records(recs, mats, textures=tex)
+    assert sc.desc.n_light_tris == 1
+    tris = sc.tris()
+    n = 4096
+    rng = np.random.default_rng(10)
+    tri = rng.integers(0, tris.shape[0], n)
+    b = rng.dirichlet([1, 1, 1], n)
+    pos = tris[tri, 0:3] * b[:, :1] + tris[tri, 3:6] * b[:, 1:2] + tris[tri, 6:9] * b[:, 2:3]
+    d = unit(rnd(n, 3, 11))
+    rec = np.zeros((n, 16), np.float32)
+    rec[:, 0:3] = pos - d
+    rec[:, 3:6] = d
+    rec[:, 6:9] = 1.0
+    rec[:, 9] = rng.choice([1.0, 1.4], n)
+    rec[:, 10:13] = pos
+    rec[:, 13] = tri.astype(np.int32).view(np.float32)
+    rec[:, 14] = rng.integers(0, 1 << 20, n).astype(np.uint32).view(np.float32)
+    rec[:, 15] = rng.integers(0, 64, n).astype(np.uint32).view(np.float32)
+    gpu.upload(sc)
+    assert same_bits(gpu.shade_hits(rec, 99), ob.shade_hits(sc, rec, 99))
+
+
+# ---- golden fixtures ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("name", ["scene_cornellbox", "scene", "scene2", "scene2_is"])
+def test_gpu_matches_committed_golden(rt, gpu, scenes, name, mode):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = scenes(name + ".txt")
+    gpu.upload(sc)
+    prim, t, pos, nrm, cnt = gpu.trace_rays(g["rays"], rt.F_BVH, want_counts=True)
+    assert np.array_equal(prim, g["prim"])                                   # ids: bit-exact
+    hit = prim >= 0
+    assert np.all(np.abs(t[hit] - g["t"][hit]) <= 1e-5 * np.abs(g["t"][hit]))  # t: 1e-5 relative
+    assert np.all(np.abs(nrm[hit] - g["normal"][hit]) <= 1e-5)               # normals: 1e-5
+    assert np.array_equal(cnt, g["counts"])
+    size, spp, bounces = int(g["img_size"]), int(g["img_spp"]), int(g["img_bounces"])
+    flags = rt.F_DEFAULT | rt.F_STATS | (rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT)
+    p = rt.default_params(sc.camera, spp=spp, width=size, height=size, max_bounces=bounces, flags=flags)
+    gpu.reset()
+    st = gpu.render(p)
+    img = gpu.readback()
+    ref = g["img_raw_sum"]
+    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 2e-2           # the stated bar
+    assert np.array_equal(img, ref)                                          # what is actually achieved
+    assert [st.paths, st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits, st.texel_fetches,
+            st.light_tests] == list(map(int, g["img_stats"]))
+
+
+# ---- options and edge cases --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
+    txt = ("SET_OUTPUT_WIDTH 48\nSET_OUTPUT_HEIGHT 40\nSET_FOCAL_LENGTH 0.5\nSET_APERTURE_RADIUS 0.05\n\n"
+           "DEF_IMAGE env\nPATH cape_hill_1k.hdr\n\nDEF_IMAGE earth\nPATH earth.ppm\n\nDEF_MODEL m\nPATH plane.obj\n\n"
+           "DEF_MODEL c\nPATH cube.obj\n\nDEF_MATERIAL a\nTYPE 3\nCOLOR 0.5 0.5 0.5\nTEXTURE earth\n\n"
+           "DEF_MATERIAL glow\nTYPE 1\nCOLOR 1 1 1\nP1 4\n\nDEF_MATERIAL glass\nTYPE 2\nP1 0.5\n\n"
+           "DEF_OBJ o\nMODEL m\nMATERIAL glow\n\nDEF_OBJ g\nMODEL c\nMATERIAL glass\n\nSET_BACKGROUND env\n\n"
+           "ADD_OBJECT\nOBJECT o\nPOSITION 0 -1 -4\nSCALE 4.0\n\nADD_OBJECT\nOBJECT g\nPOSITION 1.2 -0.3 -3.5\nROTATION 0.3 0.5 0.0\nSCALE 0.5\n\n"
+           "ADD_SPHERE\nPOSITION 0 0 -3\nRADIUS 0.5\nMATERIAL a\n\nADD_SPHERE\nPOSITION -1.2 0.2 -4\nRADIUS 0.7\nMATERIAL a\n")
+    f = tmp_path / "s.txt"
+    f.write_text(txt)
+    sc = rt.Scene.load(str(f), enable_spheres=True)
+    gpu.upload(sc)
+    m = rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT
+    for flags in [rt.F_DEFAULT | rt.F_SPHERES, rt.F_BVH | rt.F_SPHERES, rt.F_SKYBOX | rt.F_ANTIALIAS | rt.F_SPHERES,
+                  rt.F_DEFAULT]:
+        p = rt.default_params(sc.camera, spp=4, flags=flags | rt.F_STATS | m)
+        gpu.reset()
+        st = gpu.render(p)
+        o, ost = ob.render(sc, p, n_threads=4)
+        assert np.array_equal(gpu.readback(), o), flags
+        assert (st.rays, st.tri_tests, st.hits, st.texel_fetches) == (ost.rays, ost.tri_tests, ost.hits, ost.texel_fetches)
+
+
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+def test_motion_blur_and_ragged_image_sizes(ob, rt, gpu, scenes, mode):
+    sc = scenes("scene.txt")
+    gpu.upload(sc)
+    m = rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT
+    for (w, h) in [(1, 1), (7, 3), (65, 9), (100, 33)]:
+        p = rt.default_params(sc.camera, spp=3, width=w, height=h, flags=rt.F_DEFAULT | m)
+        p.cam.vel[:] = [0.2, 0.1, 0.0]
+        p.cam.ang_vel[:] = [0.0, 0.05, 0.02]
+        gpu.reset()
+        gpu.render(p)
+        o, _ = ob.render(sc, p, n_threads=4)
+        assert np.array_equal(gpu.readback(), o), (w, h)
+
+
+def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
+    mt = rt.Material(); mt.type = 3; mt.color = 0xFFFFFF; mt.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mt])
+    gpu.upload(sc)
+    for m in (rt.F_MEGAKERNEL, rt.F_WAVEFRONT):
+        p = rt.default_params(sc.camera, spp=3, width=20, height=10, flags=rt.F_DEFAULT | rt.F_STATS | m)
+        gpu.reset()
+        st = gpu.render(p)
+        assert np.array_equal(gpu.readback(), np.broadcast_to(np.float32([1, 1, 0.05]) * np.float32(0.5) * 3, (10, 20, 3)))
+        assert st.rays == st.paths == 600
+    sc = scenes("scene_cornellbox.txt")
+    gpu.upload(sc)
+    for m in (rt.F_MEGAKERNEL, rt.F_WAVEFRONT):
+        p = rt.default_params(sc.camera, spp=2, width=16, height=16, max_bounces=0, flags=rt.F_DEFAULT | rt.F_STATS | m)
+        gpu.reset()
+        st = gpu.render(p)
+        assert not gpu.readback().any() and st.rays == 0 and st.paths == 512
+    p = rt.default_params(sc.camera, spp=0, width=16, height=16)
+    gpu.reset()
+    gpu.render(p)
+    assert not gpu.readback().any()
+
+
+def test_error_codes_instead_of_exit(rt, scenes):
+    L = rt.core_lib()
+    h = C.c_void_p()
+    assert L.rt_create(C.byref(h), 0) == 0
+    try:
+        sc = scenes("scene_cornellbox.txt")
+        p = rt.default_params(sc.camera, spp=1, width=8, height=8)
+        assert L.rt_render(h, C.byref(p), None) == -3                       # RT_ERR_NO_SCENE
+        assert b"before rt_upload_scene" in L.rt_last_error(h)
+        assert L.rt_upload_scene(h, None) == -1
+        assert L.rt_upload_scene(h, C.byref(sc.desc)) == 0
+        bad = rt.RenderParams.from_buffer_copy(p); bad.cam.width = 0
+        assert L.rt_render(h, C.byref(bad), None) == -1
+        bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_RAYMARCH
+        assert L.rt_render(h, C.byref(bad), None) == -1 and b"not implemented" in L.rt_last_error(h)
+        bad = rt.RenderParams.from_buffer_copy(p); bad.band_rows, bad.band_stride, bad.band_index = 4, 2, 2
+        assert L.rt_render(h, C.byref(bad), None) == -1
+        bad = rt.RenderParams.from_buffer_copy(p); bad.cam.env_width, bad.cam.env_height = 4096, 2048   # larger than the pool
+        assert L.rt_render(h, C.byref(bad), None) == -1
+        out = np.zeros(8 * 8 * 3, np.float32)
+        assert L.rt_readback(h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, 0) == -1  # nothing rendered yet
+        assert L.rt_render(h, C.byref(p), None) == 0
+        assert L.rt_readback(h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size - 3, 0) == -1  # wrong size
+        assert L.rt_readback(h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, 0) == 0
+        # malformed BVH: child index pointing backwards (would loop forever) / bad triangle range
+        nodes = (rt.BvhNode * sc.desc.n_nodes)(*[sc.desc.nodes[i] for i in range(sc.desc.n_nodes)])
+        d2 = rt.SceneDesc.from_buffer_copy(sc.desc)
+        nodes[0].child_a = 0
+        d2.nodes = nodes
+        assert L.rt_upload_scene(h, C.byref(d2)) == -1 and b"bad child" in L.rt_last_error(h)
+        nodes[0].child_a = sc.desc.nodes[0].child_a
+        leaf = next(i for i in range(sc.desc.n_nodes) if nodes[i].child_a == -1)
+        nodes[leaf].tri_len = 10 ** 6 * 25
+        assert L.rt_upload_scene(h, C.byref(d2)) == -1 and b"bad triangle range" in L.rt_last_error(h)
+        # the good scene still renders after the failed uploads were rejected
+        assert L.rt_upload_scene(h, C.byref(sc.desc)) == 0 and L.rt_render(h, C.byref(p), None) == 0
+    finally:
+        L.rt_destroy(h)
+
+
+def test_bvh_deeper_than_stack_is_rejected(rt):
+    """A degenerate chain deeper than the LDS stack must be refused (RT_ERR_LIMIT), not overflow."""
+    depth = 40
+    n = 2 * depth + 1
+    nodes = (rt.BvhNode * n)()
+    tris = np.zeros((depth + 1, 25), np.float32)
+    for i in range(depth + 1):
+        tris[i, 0:9] = [i, 0, -5, i + 1, 0, -5, i, 1, -5]
+    # node 2k = inner (children 2k+1 leaf, 2k+2 inner/leaf)
+    for k in range(depth):
+        nd = nodes[2 * k]
+        nd.bbox_min[:] = [0, 0, -6]; nd.bbox_max[:] = [depth + 2, 2, -4]
+        nd.child_a, nd.child_b = 2 * k + 1, 2 * k + 2
+        lf = nodes[2 * k + 1]
+        lf.bbox_min[:] = [k, 0, -6]; lf.bbox_max[:] = [k + 1, 1, -4]
+        lf.child_a = lf.child_b = -1; lf.tri_offs, lf.tri_len = 25 * k, 25
+    last = nodes[2 * depth]
+    last.bbox_min[:] = [depth, 0, -6]; last.bbox_max[:] = [depth + 1, 1, -4]
+    last.child_a = last.child_b = -1; last.tri_offs, last.tri_len = 25 * depth, 25
+    m = rt.Material(); m.type = 3; m.image_offset[:] = [-1, -1, -1]
+    d = rt.SceneDesc()
+    d.tris = tris.ctypes.data_as(C.POINTER(C.c_float)); d.n_tri_floats = tris.size
+    d.nodes = nodes; d.n_nodes = n
+    marr = (rt.Material * 1)(m); d.mats = marr; d.n_mats = 1
+    L = rt.core_lib()
+    h = C.c_void_p()
+    assert L.rt_create(C.byref(h), 0) == 0
+    try:
+        assert L.rt_upload_scene(h, C.byref(d)) == -4 and b"exceeds the traversal stack" in L.rt_last_error(h)
+    finally:
+        L.rt_destroy(h)
+
+
+# ---- BASELINE-size properties (size-independent checks at full resolution) ---------------------------------
+
+def test_full_hd_properties(rt, gpu, scenes):
+    """1920x1080 (BASELINE config 2 resolution), few spp: determinism, sample-slice additivity, band gather."""
+    sc = scenes("scene.txt")
+    gpu.upload(sc)
+    W, H = 1920, 1080
+    p = rt.default_params(sc.camera, spp=2, width=W, height=H, flags=rt.F_DEFAULT | rt.F_STATS)
+    gpu.reset(); st1 = gpu.render(p); a = gpu.readback()
+    gpu.reset(); st2 = gpu.render(p); b = gpu.readback()
+    assert np.array_equal(a, b) and st1.rays == st2.rays                    # run-to-run bit reproducible
+    pw = rt.RenderParams.from_buffer_copy(p); pw.flags |= rt.F_WAVEFRONT
+    gpu.reset(); st3 = gpu.render(pw)
+    assert np.array_equal(gpu.readback(), a) and st3.rays == st1.rays       # both pipelines agree bit for bit
+    assert st1.paths == W * H * 2 and np.all(np.isfinite(a)) and a.min() >= 0
+    q = rt.RenderParams.from_buffer_copy(p); q.sample_count = 1
+    gpu.reset(); gpu.render(q); q.sample_begin = 1; gpu.render(q)
+    assert np.allclose(gpu.readback(), a, rtol=1e-6, atol=1e-7)             # slices add up
+    out = np.zeros_like(a)
+    for r in range(8):
+        q = rt.RenderParams.from_buffer_copy(p); q.band_rows, q.band_stride, q.band_index = 16, 8, r
+        gpu.reset(); gpu.render(q)
+        out[[y for y in range(H) if (y // 16) % 8 == r]] = gpu.readback()
+    assert np.array_equal(out, a)                                           # 8-way tile-row gather == 1 GPU
