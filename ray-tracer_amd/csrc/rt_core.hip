@@ -40,17 +40,21 @@ __device__ __forceinline__ int row_to_y(const Params& P, int r) {
     return (k * P.band_stride + P.band_index) * P.band_rows + (r - k * P.band_rows);
 }
 
-#ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 1  // second __launch_bounds__ argument = waves per SIMD the register allocator must allow
-#endif
+#ifndef RT_MEGA_WAVES
+#define RT_MEGA_WAVES 16  // ONE 1024-thread block per CU: its 16 waves share one LDS copy of the top of the tree.
+#endif                    // (measured: 16 waves at 128 VGPRs beat 12 waves at 161 VGPRs, profiles/r01_ab_megakernel.txt)
 template <bool STATS>
-__global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK, RT_MIN_WAVES) void rt_render_kernel(Scene sc, Params P, float* __restrict__ accum,
-                                                                              unsigned int* __restrict__ tile_counter,
-                                                                              unsigned long long* __restrict__ stats) {
-    __shared__ int lds_stack[RT_WAVES_PER_BLOCK][RT_STACK_ENTRIES][64];
+__global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc, Params P, float* __restrict__ accum,
+                                                                        unsigned int* __restrict__ tile_counter,
+                                                                        unsigned long long* __restrict__ stats, int n_cached,
+                                                                        int stack_entries) {
+    // dynamic LDS (rt_lds): [4 * n_cached node pieces][RT_MEGA_WAVES x stack_entries x 64 ints]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    int* stk = &lds_stack[wave][0][lane];
+    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES)  // item i>>2, piece i&3 (coalesced read)
+        rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
+    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+    __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
     Counters cn;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(64 * RT_WAVES_PER_BLOCK, RT_MIN_WAVES) void rt_rend
                 int hitTri;
                 float minD2;
                 f3 hitPos;
-                trace_closest<STATS>(sc, ray.o, ray.d, use_bvh, stk, hitTri, minD2, hitPos, cn);
+                trace_closest<STATS>(sc, ray.o, ray.d, use_bvh, stk, hitTri, minD2, hitPos, cn, n_cached);
                 bool handled = false;
                 if (spheres_on) {  // main.cu:305-346
                     int hitSphere = -1;
@@ -685,6 +689,7 @@ struct rt_context {
     void* d_wf = nullptr;
     int wf_slots = 0;
     int trace_lds_set = 0;   // dynamic-LDS limit already granted to the trace kernels
+    int mega_lds_set = 0;
     std::vector<hipEvent_t> ev_pool;
     unsigned int* h_pinned = nullptr;
 };
@@ -1095,10 +1100,10 @@ struct TraceCfg {
     size_t lds_bytes;
 };
 
-TraceCfg trace_cfg(rt_context* c) {
+TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES) {
     TraceCfg t;
     t.stack_entries = std::max(c->bvh_depth, 1);
-    const size_t stack_bytes = (size_t)RT_TRACE_WAVES * t.stack_entries * 64 * sizeof(int);
+    const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int);
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / 64 : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
@@ -1116,20 +1121,31 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
     return RT_OK;
 }
 
+int set_mega_lds(rt_context* c, const TraceCfg& t) {
+    if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    c->mega_lds_set = (int)t.lds_bytes;
+    return RT_OK;
+}
+
 int render_megakernel(rt_context* c, const Params& P, float* accum, bool want_stats) {
     HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+    // persistent grid: ONE block of RT_MEGA_WAVES waves per CU (its register count allows no more), never more than the work
+    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES);
+    int rc = set_mega_lds(c, tc);
+    if (rc != RT_OK) return rc;
     int occ = 0;
     const void* kfn = want_stats ? (const void*)rt_render_kernel<true> : (const void*)rt_render_kernel<false>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * RT_WAVES_PER_BLOCK, 0) != hipSuccess || occ < 1) occ = 2;
-    const int max_blocks = c->num_cus * occ;
-    const int want_blocks = (P.n_tiles + RT_WAVES_PER_BLOCK - 1) / RT_WAVES_PER_BLOCK;
-    const int blocks = std::max(1, std::min(max_blocks, want_blocks));
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
+    const int want_blocks = (P.n_tiles + RT_MEGA_WAVES - 1) / RT_MEGA_WAVES;
+    const int blocks = std::max(1, std::min(c->num_cus * occ, want_blocks));
     if (want_stats)
-        hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
-                           c->d_tile_counter, c->d_stats);
+        hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, accum,
+                           c->d_tile_counter, c->d_stats, tc.n_cached, tc.stack_entries);
     else
-        hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(64 * RT_WAVES_PER_BLOCK), 0, c->stream, c->sc, P, accum,
-                           c->d_tile_counter, c->d_stats);
+        hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, accum,
+                           c->d_tile_counter, c->d_stats, tc.n_cached, tc.stack_entries);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }

@@ -432,12 +432,25 @@ __device__ __forceinline__ int trav_spheres(const Scene& sc, Trav& t, f3& sPos) 
 // Whole query for one lane (megakernel mode): steps until done.
 template <bool STATS>
 __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool use_bvh, int* stk, int& hitTri,
-                                              float& minD2, f3& hitPos, Counters& cn) {
+                                              float& minD2, f3& hitPos, Counters& cn, int n_cached = 0) {
     Trav t;
     if (STATS) cn.rays++;
     trav_begin(sc, t, o, d);
     if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
-    while (t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn);
+#ifndef RT_MEGA_WHILE
+#define RT_MEGA_WHILE 0  // measured slower than one mixed step per iteration (profiles/r01_ab_megakernel.txt)
+#endif
+#if RT_MEGA_WHILE
+    // "while-while": all lanes first walk inner nodes until each holds a triangle (or is done), then
+    // the wave tests triangles until each lane is back at an inner node.  Same per-lane visit
+    // order; measured faster than mixing both kinds in every iteration when lanes cannot be refilled.
+    while (t.cur != RT_TRAV_DONE) {
+        while (t.cur >= 0 && t.cur < sc.n_inner) trav_step<STATS>(sc, t, stk, cn, n_cached);
+        while (t.cur >= sc.n_inner || t.cur == RT_TRAV_EMPTY) trav_step<STATS>(sc, t, stk, cn, n_cached);
+    }
+#else
+    while (t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn, n_cached);
+#endif
     hitTri = t.hitTri;
     minD2 = t.minD2;
     hitPos = t.hitPos;
