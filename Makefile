@@ -11,7 +11,7 @@ CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unu
 HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Iinclude
 
-all: $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so oracle
+all: $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so $(LIBDIR)/rtcli oracle
 
 $(LIBDIR)/librt_scene.so: $(PKG)/csrc/host/rt_scene.cpp include/rt_scene.h include/rt.h
 	@mkdir -p $(LIBDIR)
@@ -20,6 +20,9 @@ $(LIBDIR)/librt_scene.so: $(PKG)/csrc/host/rt_scene.cpp include/rt_scene.h inclu
 $(LIBDIR)/librt_amd.so: $(PKG)/csrc/rt_core.hip $(wildcard $(PKG)/csrc/*.h) include/rt.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+
+$(LIBDIR)/rtcli: $(PKG)/csrc/cli/rtcli.cpp $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so include/rt.h include/rt_scene.h
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lrt_scene -lrt_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 oracle: oracle/lib/librt_oracle.so
 oracle/lib/librt_oracle.so: oracle/rt_oracle.cpp oracle/rt_pmath_oracle.h include/rt.h

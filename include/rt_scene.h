@@ -80,7 +80,7 @@ int rt_noise_texture(int w, int h, float* out_rgb);
  * gamma 2.2 as stbi_loadf does for LDR input), .pfm.  malloc'ed result. */
 int rt_image_load(const char* path, float** out_rgb, int* w, int* h);
 
-/* Texture::saveImgData (texture.cpp:49-60).  By extension: .ppm = 8-bit
+/* Texture::saveImgData (texture.cpp:49-60).  By extension: .png / .ppm = 8-bit
  * with the reference's unclamped `(unsigned char)(v*255)` cast, .pfm = raw
  * float, .hdr = Radiance RGBE (flat). */
 int rt_image_save(const char* path, const float* rgb, int w, int h);

@@ -1,0 +1,110 @@
+// rtcli -- the caller of the render core: what main() is in the reference (src/main.cu:410-517):
+//   parse scene -> assemble arrays (+BVH) -> rt_upload_scene -> rt_render -> rt_readback -> image file.
+// Unlike the reference (hard-coded SCENE_CONFIG_PATH / OUTPUT_IMAGE_PATH macros, config.h:20-21, argv ignored)
+// everything is a command-line option.
+//
+//   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
+//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront] [--stats]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt.h"
+#include "rt_scene.h"
+
+static int usage() {
+    fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
+                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront] [--stats]\n");
+    return 2;
+}
+
+int main(int argc, char** argv) {
+    std::string scene, asset_root, out = "output.png", env;
+    int spp = -1, bounces = 6, W = 0, H = 0, device = 0;
+    unsigned seed = 37811;
+    bool hdr = false, spheres = false, bvh = true, wavefront = false, want_stats = false;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--scene") scene = next();
+        else if (a == "--asset-root") asset_root = next();
+        else if (a == "--out") out = next();
+        else if (a == "--env") env = next();
+        else if (a == "--spp") spp = atoi(next());
+        else if (a == "--bounces") bounces = atoi(next());
+        else if (a == "--seed") seed = (unsigned)strtoul(next(), nullptr, 10);
+        else if (a == "--device") device = atoi(next());
+        else if (a == "--size") { if (sscanf(next(), "%dx%d", &W, &H) != 2) return usage(); }
+        else if (a == "--hdr") hdr = true;            // HDRI_EXPORT, config.h:12
+        else if (a == "--spheres") spheres = true;    // ENABLE_SPHERES, config.h:13
+        else if (a == "--no-bvh") bvh = false;        // ENABLE_BVH, config.h:16
+        else if (a == "--wavefront") wavefront = true;
+        else if (a == "--stats") want_stats = true;
+        else return usage();
+    }
+    if (scene.empty()) return usage();
+
+    rt_host_scene* hs = nullptr;
+    if (rt_scene_load(scene.c_str(), asset_root.empty() ? nullptr : asset_root.c_str(), env.empty() ? nullptr : env.c_str(),
+                      spheres ? 1 : 0, 0, 0, &hs) != RT_OK) {
+        fprintf(stderr, "scene: %s\n", rt_scene_last_error());
+        return 1;
+    }
+    rt_scene_desc desc;
+    rt_camera cam;
+    rt_scene_get_desc(hs, &desc);
+    rt_scene_get_camera(hs, &cam);
+    printf("Number of triangles: %zu, BVH nodes: %d, materials: %zu\n", desc.n_tri_floats / RT_TRI_FLOATS, desc.n_nodes, desc.n_mats);
+    printf("num important tris: %d\n", desc.n_light_tris);          // main.cu:442
+    printf("Image data length: %zu\n", desc.n_tex_floats);          // main.cu:456
+
+    rt_context* ctx = nullptr;
+    if (rt_create(&ctx, device) != RT_OK) {
+        fprintf(stderr, "rt_create failed: no usable HIP device (there is no CPU fallback)\n");
+        return 1;
+    }
+    if (rt_upload_scene(ctx, &desc) != RT_OK) {
+        fprintf(stderr, "upload: %s\n", rt_last_error(ctx));
+        return 1;
+    }
+    rt_render_params p;
+    memset(&p, 0, sizeof(p));
+    p.cam = cam;
+    if (W > 0 && H > 0) { p.cam.width = W; p.cam.height = H; }
+    p.max_bounces = bounces;
+    p.flags = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | (bvh ? RT_F_BVH : 0) | (spheres ? RT_F_SPHERES : 0) |
+              (wavefront ? RT_F_WAVEFRONT : 0) | (want_stats ? RT_F_STATS : 0);
+    p.seed = seed;
+    p.sample_begin = 0;
+    p.sample_count = spp > 0 ? spp : cam.num_samples;
+    p.band_stride = 1;
+    p.background[0] = 1.0f; p.background[1] = 1.0f; p.background[2] = 0.05f;  // config.h:7
+    p.background_brightness = 0.5f;                                          // config.h:6
+    printf("begin rendering\n");                                             // main.cu:470
+    rt_render_stats st;
+    if (rt_render(ctx, &p, &st) != RT_OK) {
+        fprintf(stderr, "render: %s\n", rt_last_error(ctx));
+        return 1;
+    }
+    printf("done rendering\nRender time: %g ms\n", st.kernel_ms);            // main.cu:493, 498
+    if (want_stats)
+        printf("paths %llu rays %llu (%.1f Mrays/s) inner %llu leaf %llu tri %llu\n", (unsigned long long)st.paths,
+               (unsigned long long)st.rays, st.rays / (st.kernel_ms * 1e3), (unsigned long long)st.inner_visits,
+               (unsigned long long)st.leaf_visits, (unsigned long long)st.tri_tests);
+    std::vector<float> img((size_t)p.cam.width * p.cam.height * 3);
+    if (rt_readback(ctx, img.data(), img.size(), hdr ? RT_READ_AVERAGE : RT_READ_TONEMAPPED) != RT_OK) {
+        fprintf(stderr, "readback: %s\n", rt_last_error(ctx));
+        return 1;
+    }
+    if (rt_image_save(out.c_str(), img.data(), p.cam.width, p.cam.height) != RT_OK) {
+        fprintf(stderr, "save: %s\n", rt_scene_last_error());
+        return 1;
+    }
+    printf("Saved output\n");                                                // main.cu:515
+    rt_destroy(ctx);
+    rt_scene_free(hs);
+    return 0;
+}

@@ -861,13 +861,84 @@ int rt_image_load(const char* path, float** out_rgb, int* w, int* h) {
     return RT_OK;
 }
 
+namespace {
+// Minimal PNG encoder (8-bit RGB, zlib "stored" blocks): enough for the reference's stbi_write_png output stage.
+uint32_t crc32_update(uint32_t crc, const unsigned char* d, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ d[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<unsigned char>& v, uint32_t x) {
+    v.push_back((unsigned char)(x >> 24)); v.push_back((unsigned char)(x >> 16));
+    v.push_back((unsigned char)(x >> 8)); v.push_back((unsigned char)x);
+}
+void png_chunk(FILE* f, const char* type, const std::vector<unsigned char>& data) {
+    std::vector<unsigned char> hdr;
+    put_be32(hdr, (uint32_t)data.size());
+    fwrite(hdr.data(), 1, 4, f);
+    fwrite(type, 1, 4, f);
+    if (!data.empty()) fwrite(data.data(), 1, data.size(), f);
+    uint32_t crc = crc32_update(0xffffffffu, (const unsigned char*)type, 4);
+    if (!data.empty()) crc = crc32_update(crc, data.data(), data.size());
+    crc ^= 0xffffffffu;
+    std::vector<unsigned char> tail;
+    put_be32(tail, crc);
+    fwrite(tail.data(), 1, 4, f);
+}
+void write_png(FILE* f, const unsigned char* rgb8, int w, int h) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    std::vector<unsigned char> ihdr;
+    put_be32(ihdr, (uint32_t)w);
+    put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(f, "IHDR", ihdr);
+    std::vector<unsigned char> raw;  // filter byte 0 + row
+    raw.reserve((size_t)h * (3 * (size_t)w + 1));
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb8 + (size_t)y * w * 3, rgb8 + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<unsigned char> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    size_t pos = 0;
+    do {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xff)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xff)); z.push_back((unsigned char)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    } while (pos < raw.size());
+    put_be32(z, (b << 16) | a);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", std::vector<unsigned char>());
+}
+}  // namespace
+
 int rt_image_save(const char* path, const float* rgb, int w, int h) {
     if (!path || !rgb || w <= 0 || h <= 0) return fail("bad image arguments");
     const std::string p(path);
     FILE* f = fopen(path, "wb");
     if (!f) return fail("could not open for writing: " + p);
     const size_t n = (size_t)w * h * 3;
-    if (ends_with(p, ".ppm")) {
+    if (ends_with(p, ".png")) {
+        std::vector<unsigned char> img(n);
+        // texture.cpp:55: static_cast<unsigned char>(data[i] * 255), no clamp
+        for (size_t i = 0; i < n; i++) img[i] = (unsigned char)(int)(rgb[i] * 255);
+        write_png(f, img.data(), w, h);
+    } else if (ends_with(p, ".ppm")) {
         fprintf(f, "P6\n%d %d\n255\n", w, h);
         std::vector<unsigned char> img(n);
         // texture.cpp:55: static_cast<unsigned char>(data[i] * 255), no clamp.
@@ -895,7 +966,7 @@ int rt_image_save(const char* path, const float* rgb, int w, int h) {
         }
     } else {
         fclose(f);
-        return fail("unsupported output format (need .ppm/.pfm/.hdr): " + p);
+        return fail("unsupported output format (need .png/.ppm/.pfm/.hdr): " + p);
     }
     fclose(f);
     return RT_OK;
