@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
             }
             if (!__any(alive)) break;
             if (alive) {  // one iteration of the bounce loop, main.cu:220-389
-                rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce);
+                const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
                 int hitTri;
                 float minD2;
                 f3 hitPos;
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
                         // material id from the sphere record (the reference reads materials[i+4], main.cu:341)
                         const int mat = __float_as_int(sc.spheres[2 * hitSphere + 1].x);
                         if (STATS) cn.hits++;
-                        shade_sphere<STATS>(sc, ray, sNrm, sPos, mat, rng, cn);
+                        shade_sphere<STATS>(sc, ray, sNrm, sPos, mat, rng, bb, cn);
                         handled = true;  // `continue` at main.cu:343: no renormalise
                     }
                 }
                 if (!handled) {
                     if (hitTri >= 0) {
                         if (STATS) cn.hits++;
-                        const bool terminated = shade_triangle<STATS>(sc, ray, hitPos, hitTri, rng, cn);
+                        const bool terminated = shade_triangle<STATS>(sc, ray, hitPos, hitTri, rng, bb, cn);
                         if (terminated) {  // main.cu:357-360
                             const f3 e = ray.emission * ray.thr;
                             color.x += e.x; color.y += e.y; color.z += e.z;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Para
                 bounce = packed & 0xff;
                 ray.o = mk(0.f, 0.f, 0.f);
                 rng.init(P.seed, pixel, (uint32_t)(P.sample_begin + k - 1));
-                rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce);
+                const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
                 const f3 hitPos = mk(h.x, h.y, h.z);
                 const int tri = __float_as_int(h.w);
                 bool terminated = false;
@@ -270,10 +270,10 @@ __global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Para
                     const float4 s0 = sc.spheres[2 * si];
                     const int mat = __float_as_int(sc.spheres[2 * si + 1].x);
                     if (STATS) cn.hits++;
-                    shade_sphere<STATS>(sc, ray, normalize(hitPos - mk(s0.x, s0.y, s0.z)), hitPos, mat, rng, cn);
+                    shade_sphere<STATS>(sc, ray, normalize(hitPos - mk(s0.x, s0.y, s0.z)), hitPos, mat, rng, bb, cn);
                 } else if (tri >= 0) {
                     if (STATS) cn.hits++;
-                    terminated = shade_triangle<STATS>(sc, ray, hitPos, tri, rng, cn);
+                    terminated = shade_triangle<STATS>(sc, ray, hitPos, tri, rng, bb, cn);
                     if (terminated) {  // main.cu:357-360
                         const f3 e = ray.emission * ray.thr;
                         color.x += e.x; color.y += e.y; color.z += e.z;
@@ -531,11 +531,10 @@ __global__ void rt_shade_kernel(Scene sc, const float* __restrict__ in, size_t n
     const int tri = __float_as_int(q[13]);
     Rng rng;
     rng.init(seed, __float_as_uint(q[14]), __float_as_uint(q[15]));
-    rng.seek(RT_RNG_DIM_BOUNCE0);
     Counters cn;
     cn.clear();
     bool term = true;
-    if (tri >= 0 && tri < sc.n_tris) term = shade_triangle<false>(sc, ray, hitPos, tri, rng, cn);
+    if (tri >= 0 && tri < sc.n_tris) term = shade_triangle<false>(sc, ray, hitPos, tri, rng, RT_RNG_DIM_BOUNCE0 >> 2, cn);
     o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z;
     o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
     o[6] = ray.thr.x; o[7] = ray.thr.y; o[8] = ray.thr.z;
@@ -617,8 +616,9 @@ __global__ void rt_debug_kernel(int op, const float* __restrict__ in, size_t n, 
             const float* q = in + r * 4;
             Rng rng;
             rng.init(__float_as_uint(q[0]), __float_as_uint(q[1]), __float_as_uint(q[2]));
-            rng.seek(__float_as_uint(q[3]) & ~3u);
-            for (int k = 0; k < 4; k++) out[r * 4 + k] = __uint_as_float(rng.raw());
+            const uint4 w = rng.block(__float_as_uint(q[3]) >> 2);
+            out[r * 4] = __uint_as_float(w.x); out[r * 4 + 1] = __uint_as_float(w.y);
+            out[r * 4 + 2] = __uint_as_float(w.z); out[r * 4 + 3] = __uint_as_float(w.w);
             break;
         }
         case RT_OP_ENV_INDEX: {

@@ -141,36 +141,23 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Sequential view of one (pixel, sample) stream: draws are taken from consecutive
-// dimensions; a Philox block (4 dims) is generated when first touched.
+// One (pixel, sample) stream.  Draws are addressed by DIMENSION (rt.h); a Philox block yields the
+// four dimensions 4b .. 4b+3.  Every call site below names its dimensions statically, so Philox is
+// generated at a handful of places (camera, lens, one or two blocks per bounce) and nothing but the
+// three key words stays live across the traversal.
 struct Rng {
     uint32_t seed, pixel, sample;
-    uint32_t dim;
-    uint32_t block;  // block held in w, 0xffffffff = none
-    uint32_t w0, w1, w2, w3;
-    __device__ __forceinline__ void init(uint32_t s, uint32_t p, uint32_t k) {
-        seed = s; pixel = p; sample = k; dim = 0; block = 0xffffffffu;
-    }
-    __device__ __forceinline__ void seek(uint32_t d) { dim = d; }
-    __device__ __forceinline__ uint32_t raw() {
-        const uint32_t b = dim >> 2;
-        if (b != block) {
-            uint32_t o[4];
-            philox4x32_10(pixel, sample, b, RT_RNG_TAG, seed, RT_RNG_KEY1, o);
-            w0 = o[0]; w1 = o[1]; w2 = o[2]; w3 = o[3];
-            block = b;
-        }
-        const uint32_t k = dim & 3u;
-        dim++;
-        return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
-    }
-    __device__ __forceinline__ float uniform() { return (float)((raw() >> 8) + 1u) * (1.0f / 16777216.0f); }
-    __device__ __forceinline__ float normal() {
-        const float u1 = uniform();
-        const float u2 = uniform();
-        return sqrtf(-2.0f * pm::log(u1)) * pm::cos(6.2831855f * u2);
+    __device__ __forceinline__ void init(uint32_t s, uint32_t p, uint32_t k) { seed = s; pixel = p; sample = k; }
+    __device__ __forceinline__ uint4 block(uint32_t b) const {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, b, RT_RNG_TAG, seed, RT_RNG_KEY1, o);
+        return make_uint4(o[0], o[1], o[2], o[3]);
     }
 };
+__device__ __forceinline__ float u01(uint32_t x) { return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f); }  // (0,1]
+__device__ __forceinline__ float gauss(uint32_t a, uint32_t b) {  // normal from two consecutive dimensions
+    return sqrtf(-2.0f * pm::log(u01(a))) * pm::cos(6.2831855f * u01(b));
+}
 
 // ------------------------------------------------------------------ counters
 struct Counters {
@@ -475,9 +462,7 @@ __device__ __forceinline__ f3 fetch_texel(const Scene& sc, long long i) {
 }
 
 // Material::randSphereVec, material.h:130-140 (same body: Vec3::randSphere, Sphere::randSphereVec)
-__device__ __forceinline__ f3 rand_sphere_vec(Rng& rng) {
-    const float r1 = rng.uniform();
-    const float r2 = rng.uniform();
+__device__ __forceinline__ f3 rand_sphere_vec(float r1, float r2) {
     const float theta = r1 * 2.0f * 3.14159f;
     const float phi = pm::acos(2.0f * r2 - 1.0f);
     float sp, cp, st, ct;
@@ -487,8 +472,8 @@ __device__ __forceinline__ f3 rand_sphere_vec(Rng& rng) {
 }
 
 // Material::randCosineHemisphere, material.h:152-161
-__device__ __forceinline__ f3 rand_cosine_hemisphere(f3 normal, Rng& rng) {
-    const f3 s = rand_sphere_vec(rng);
+__device__ __forceinline__ f3 rand_cosine_hemisphere(f3 normal, float r1, float r2) {
+    const f3 s = rand_sphere_vec(r1, r2);
     const float cos_theta = dot(s, normal);
     if (cos_theta > 0.0f) return s * sqrtf(cos_theta);
     return s * -1.0f * sqrtf(-cos_theta);
@@ -533,8 +518,10 @@ __device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int tri, f3 hitPo
 
 // Material::reflect, material.h:41-106.  Returns true when the path terminates.
 template <bool STATS>
-__device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, Rng& rng,
-                                               Counters& cn) {
+// The bounce's dimensions 8+8j .. 15+8j are Philox blocks bb and bb+1 (bb = 2 + 2j): A = dims k0..k3,
+// B = dims k4..k7, consumed in the reference's call order.
+__device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, const Rng& rng,
+                                               uint32_t bb, Counters& cn) {
     const HitFrame hf = hit_frame(sc, tri, hitPos);
     const f3 normal = hf.normal;
     int type = 127;  // out-of-range material id -> "the color of error"
@@ -568,14 +555,16 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
     switch (type) {
         case 0: {  // reflectType0, material.h:182-202
             ray.o = hitPos;
-            if (rng.uniform() < p1) {
+            const uint4 A = rng.block(bb);
+            if (u01(A.x) < p1) {
                 ray.thr = ray.thr * mk(0.95f, 0.95f, 0.95f);
                 ray.d = reflect(ray.d, normal);
             } else {
                 ray.thr = ray.thr * clr;
-                const float g0 = rng.normal();
-                const float g1 = rng.normal();
-                const float g2 = rng.normal();
+                const uint4 B = rng.block(bb + 1);
+                const float g0 = gauss(A.y, A.z);
+                const float g1 = gauss(A.w, B.x);
+                const float g2 = gauss(B.y, B.z);
                 ray.d = reflect(ray.d, normalize(normal + mk(g0, g1, g2) * p2));
             }
             ray.o = ray.o + ray.d * 1e-5f;
@@ -603,7 +592,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
                 const double x = (double)(1 - cos_theta);
                 const double x2 = x * x;
                 r0 = (float)((double)r0 + (double)(1 - r0) * (x2 * x2 * x));
-                if (r0 > rng.uniform()) will_refract = false;
+                if (r0 > u01(rng.block(bb).x)) will_refract = false;
             }
             if (will_refract) {
                 ray.d = refract(ray.d, normal2, ri);
@@ -618,7 +607,8 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             const f3 normal2 = (dot(normal, ray.d) < 0.0f) ? normal : (normal * -1.0f);
             ray.thr = ray.thr * clr0;
             ray.o = hitPos;
-            ray.d = normalize(normal2 + rand_sphere_vec(rng));
+            const uint4 A = rng.block(bb);
+            ray.d = normalize(normal2 + rand_sphere_vec(u01(A.x), u01(A.y)));
             ray.o = ray.o + ray.d * 1e-5f;
             return false;
         }
@@ -626,7 +616,8 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.thr = ray.thr * clr;
             ray.o = hitPos;
             ray.d = reflect(ray.d, normal);
-            ray.d = ray.d + rand_sphere_vec(rng) * p1;
+            const uint4 A = rng.block(bb);
+            ray.d = ray.d + rand_sphere_vec(u01(A.x), u01(A.y)) * p1;
             ray.o = ray.o + ray.d * 1e-5f;
             return false;
         }
@@ -635,20 +626,24 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.o = hitPos;
             f3 outgoing;
             bool sampledLight = false;
-            if (sc.n_lights > 0 && rng.uniform() < 0.5f) {
-                const uint32_t pick = rng.raw() % (uint32_t)sc.n_lights;
-                const float4* L = sc.lights + 5 * (size_t)pick;
-                const float4 l0 = L[0], l3 = L[3], l4 = L[4];
-                const float r1 = rng.uniform();
-                const float r2 = rng.uniform();
-                outgoing = itri_sample(hitPos, r1, r2, mk(l0.x, l0.y, l0.z), mk(l3.y, l3.z, l3.w), mk(l4.x, l4.y, l4.z));
-                sampledLight = true;
+            const uint4 A = rng.block(bb);
+            if (sc.n_lights > 0) {
+                if (u01(A.x) < 0.5f) {  // dims k0 (choice), k1 (raw pick), k2, k3
+                    const uint32_t pick = A.y % (uint32_t)sc.n_lights;
+                    const float4* L = sc.lights + 5 * (size_t)pick;
+                    const float4 l0 = L[0], l3 = L[3], l4 = L[4];
+                    outgoing = itri_sample(hitPos, u01(A.z), u01(A.w), mk(l0.x, l0.y, l0.z), mk(l3.y, l3.z, l3.w), mk(l4.x, l4.y, l4.z));
+                    sampledLight = true;
+                } else {
+                    outgoing = rand_cosine_hemisphere(normal2, u01(A.y), u01(A.z));  // k1, k2
+                }
             } else {
-                outgoing = rand_cosine_hemisphere(normal2, rng);
+                outgoing = rand_cosine_hemisphere(normal2, u01(A.x), u01(A.y));  // no choice draw without lights
             }
             float cos_theta = dot(normal2, outgoing);
-            if (cos_theta <= 0.0f && sampledLight) {
-                outgoing = rand_cosine_hemisphere(normal2, rng);
+            if (cos_theta <= 0.0f && sampledLight) {  // redraw: k4, k5
+                const uint4 B = rng.block(bb + 1);
+                outgoing = rand_cosine_hemisphere(normal2, u01(B.x), u01(B.y));
                 cos_theta = dot(normal2, outgoing);
             }
             if (cos_theta < 0.0f) cos_theta = 0.0f;
@@ -691,8 +686,8 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
 
 // Sphere::hitSphere, sphere.h:77-88
 template <bool STATS>
-__device__ __forceinline__ void shade_sphere(const Scene& sc, PathState& ray, f3 normal, f3 hitPos, int mat, Rng& rng,
-                                             Counters& cn) {
+__device__ __forceinline__ void shade_sphere(const Scene& sc, PathState& ray, f3 normal, f3 hitPos, int mat, const Rng& rng,
+                                             uint32_t bb, Counters& cn) {
     const float u = pm::atan2(ray.d.z, ray.d.x) / (2.0f * 3.14159f) + 0.5f;
     const float v = -pm::asin(ray.d.y) / (2.0f * 3.14159f) + 0.5f;
     f3 clr = mk(1.0f, 0.0f, 1.0f);
@@ -709,7 +704,8 @@ __device__ __forceinline__ void shade_sphere(const Scene& sc, PathState& ray, f3
     }
     ray.thr = ray.thr * clr;
     ray.o = hitPos;
-    ray.d = normalize(normal + rand_sphere_vec(rng));
+    const uint4 A = rng.block(bb);
+    ray.d = normalize(normal + rand_sphere_vec(u01(A.x), u01(A.y)));
     ray.o = ray.o + ray.d * 1e-5f;
 }
 
@@ -735,11 +731,11 @@ __device__ __forceinline__ f3 tone_map(f3 c) {
 }
 
 // ------------------------------------------------------------------ camera (main.cu:173-217)
-__device__ __forceinline__ void camera_ray(const Params& P, int x, int y, Rng& rng, f3& origin, f3& dir) {
+__device__ __forceinline__ void camera_ray(const Params& P, int x, int y, const Rng& rng, f3& origin, f3& dir) {
     const float sx = (float)x / (float)P.width - 0.5f;
     const float sy = -(float)y / (float)P.height + 0.5f;
-    rng.seek(RT_RNG_DIM_CAMERA);
-    const float t = rng.uniform();
+    const uint4 C = rng.block(RT_RNG_DIM_CAMERA >> 2);  // dims 0 time, 1-2 anti-alias jitter
+    const float t = u01(C.x);
     const f3 pos0 = ld3(P.cam_pos);
     const f3 camPos = lerp3(pos0, pos0 + ld3(P.cam_vel), t);
     f3 up, right, forward;
@@ -765,16 +761,16 @@ __device__ __forceinline__ void camera_ray(const Params& P, int x, int y, Rng& r
     }
     float aa1 = 0.0f, aa2 = 0.0f;
     if (P.flags & RT_F_ANTIALIAS) {
-        aa1 = rng.uniform() - 0.5f;
-        aa2 = rng.uniform() - 0.5f;
+        aa1 = u01(C.y) - 0.5f;
+        aa2 = u01(C.z) - 0.5f;
     }
     const f3 s = forward * P.focal + right * (sx + aa1 / (float)P.width) + up * (sy + aa2 / (float)P.height);
     dir = normalize(s);
     origin = camPos;
     if (P.aperture > 1e-5f && (P.flags & RT_F_DEFOCUS)) {  // randomPointInDisk, main.cu:119-125
-        rng.seek(RT_RNG_DIM_LENS);
-        const float theta = 2.0f * 3.14159f * rng.uniform();
-        const float r = sqrtf(rng.uniform()) * (P.aperture * 0.5f);
+        const uint4 Ln = rng.block(RT_RNG_DIM_LENS >> 2);  // dims 4 theta, 5 radius
+        const float theta = 2.0f * 3.14159f * u01(Ln.x);
+        const float r = sqrtf(u01(Ln.y)) * (P.aperture * 0.5f);
         float st, ct;
         pm::sincos(theta, &st, &ct);
         const float lx = r * ct;
