@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--bounces", type=int, default=6)
     ap.add_argument("--partition", choices=["samples", "rows"], default="samples")
-    ap.add_argument("--mode", choices=["wavefront", "megakernel"], default="megakernel")
+    ap.add_argument("--mode", choices=["wavefront", "megakernel", "lockstep"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=0, help="use the synthetic instanced field instead of --scene")
@@ -86,7 +86,7 @@ def main():
     r = rt.Renderer(local_rank)
     r.upload(scene)
     p = rt.default_params(scene.camera, spp=spp, width=W, height=H, max_bounces=args.bounces)
-    p.flags |= rt.F_MEGAKERNEL if args.mode == "megakernel" else rt.F_WAVEFRONT
+    p.flags |= rt.MODE_FLAGS[args.mode]
     if world > 1:
         D.partition_params(p, rank, world, args.partition, spp)
     rows = rt.band_rows_of(p)
@@ -152,6 +152,11 @@ def main():
             dom_bytes = 56 * st_counts.inner_visits + 8 * st_counts.leaf_visits + 36 * st_counts.tri_tests
             dom_ms = st_prof.trace_ms
             launches = st_prof.trace_launches
+        elif args.mode == "megakernel" and st_prof.trace_launches > 0:
+            # path-parallel fused kernel: everything but the 12 bytes per pixel of the accumulator update, which
+            # rt_sum_samples_kernel does; duration of its launches alone (RT_F_PROFILE)
+            dom_kernel, dom_bytes = "rt_render_paths_kernel", abytes - 12 * rows * W
+            dom_ms, launches = st_prof.trace_ms, st_prof.trace_launches
         else:
             dom_kernel, dom_bytes, dom_ms, launches = "rt_render_kernel", abytes, k_ms, 1
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9

@@ -116,10 +116,13 @@ enum {
     RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9  (reserved, rejected) */
     RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14 (reserved, rejected) */
     RT_F_STATS = 1 << 8,        /* count rays / node visits / triangle tests */
-    RT_F_MEGAKERNEL = 1 << 9,   /* force the fused persistent kernel (lane = pixel) */
+    RT_F_MEGAKERNEL = 1 << 9,   /* force the fused persistent kernel (path-parallel: lanes take (pixel, sample) paths
+                                   one by one, per-path radiance summed per pixel in sample order afterwards) */
+    RT_F_LOCKSTEP = 1 << 12,    /* fused kernel in lock step instead: one lane owns a pixel for the whole call, no
+                                   per-path radiance buffer (slower; bit-identical sums) */
     RT_F_WAVEFRONT = 1 << 11,   /* force the wavefront pipeline (logic kernel + persistent trace kernel);
                                    with neither bit the library picks (currently the fused kernel) */
-    RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every trace-kernel launch (rt_render_stats.trace_ms) */
+    RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every launch of the dominant kernel (rt_render_stats.trace_ms) */
     RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
 };
 
@@ -151,7 +154,8 @@ typedef struct rt_render_stats {
     uint64_t hits;          /* bounces that hit a triangle or sphere */
     uint64_t texel_fetches; /* material texel fetches + env fetches */
     uint64_t light_tests;   /* ImportanceTri::pdf_value calls, material.h:315-323 */
-    double trace_ms;        /* RT_F_PROFILE: summed HIP-event time of the rt_trace_kernel launches */
+    double trace_ms;        /* RT_F_PROFILE: summed HIP-event time of the launches of rt_trace_kernel (wavefront)
+                               or rt_render_paths_kernel (fused) */
     uint32_t iterations;    /* wavefront iterations (logic + trace launch pairs) of this call */
     uint32_t trace_launches; /* launches covered by trace_ms */
 } rt_render_stats;

@@ -81,6 +81,9 @@ F_STATS = 1 << 8
 F_MEGAKERNEL = 1 << 9
 F_PROFILE = 1 << 10
 F_WAVEFRONT = 1 << 11
+F_LOCKSTEP = 1 << 12
+# the three schedules of the same arithmetic (bit-identical results)
+MODE_FLAGS = {"megakernel": F_MEGAKERNEL, "lockstep": F_MEGAKERNEL | F_LOCKSTEP, "wavefront": F_WAVEFRONT}
 F_DEFAULT = F_SKYBOX | F_ANTIALIAS | F_DEFOCUS | F_BVH
 READ_RAW_SUM, READ_AVERAGE, READ_TONEMAPPED = 0, 1, 2
 (OP_TRI_INTERSECT, OP_AABB_DIST, OP_SPHERE, OP_FLOOR, OP_ITRI_PDF, OP_ITRI_SAMPLE, OP_ATTRACTOR_PDF,

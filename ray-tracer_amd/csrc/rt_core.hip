@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
     Counters cn;
     cn.clear();
+    [[maybe_unused]] const unsigned long long plife0 = RT_PROF_CLOCK();
 
     for (;;) {
         unsigned int tile = 0;
@@ -105,7 +106,12 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
                 int hitTri;
                 float minD2;
                 f3 hitPos;
+                [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
                 trace_closest<STATS>(sc, ray.o, ray.d, use_bvh, stk, hitTri, minD2, hitPos, cn, n_cached);
+                [[maybe_unused]] const unsigned long long pc1 = RT_PROF_CLOCK();
+                RT_PROF_COUNT(cn, 2, pc1 - pc0);
+                RT_PROF_COUNT(cn, 3, 1);
+                RT_PROF_LANE(cn, 4);
                 bool handled = false;
                 if (spheres_on) {  // main.cu:305-346
                     int hitSphere = -1;
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
                 }
                 bounce++;
                 if (bounce >= P.max_bounces) alive = false;  // path exhausted: contributes 0
+                RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc1);
             }
         }
         if (in_image) {
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
         }
     }
 
+    RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {  // wave-reduce, one atomic per counter per wave
         uint32_t v[8] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights};
 #pragma unroll
@@ -174,7 +182,251 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
         }
+#ifdef RT_CYCLE_PROF
+        for (int i = 0; i < 8; i++) {
+            unsigned long long s = cn.prof[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&stats[8 + i], s);
+        }
+#endif
     }
+}
+
+// ------------------------------------------------------------------------------- path-parallel fused kernel
+//
+// Same arithmetic per path and the same per-pixel sum, different schedule.  rt_render_kernel above
+// runs "trace one ray, shade one hit" in lock step: every lane of a wave waits for the longest
+// traversal of each round (measured: 29.7 of 64 lanes active per traversal iteration) and a pixel's
+// samples are one serial chain.  Here
+//  * the unit of work is ONE PATH (pixel, sample).  A path writes its radiance to samples[path];
+//    rt_sum_samples_kernel then adds a pixel's samples in sample order (c = 0; c += e_k; accum += c,
+//    the very additions of the lock-step kernel), so the raw sums are bit-identical;
+//  * a lane is in one of four phases and the wave keeps stepping the traversal of the lanes that
+//    hold a ray; the others wait until RT_REGEN_MIN of them have gathered and then ONE "vertex pass"
+//    serves them all: shade the hit (or the environment), store a finished path and take the next
+//    one, generate its camera ray, start the next traversal;
+//  * a wave takes paths in batches of RT_PATH_BATCH (one atomic) and hands them to lanes one by one.
+// Path index p within a chunk of S samples: p = ((tile * S + k) * 64 + pixel-in-tile), so the 64
+// lanes of a wave mostly hold neighbouring pixels of one sample.
+#ifndef RT_REGEN_MIN
+#define RT_REGEN_MIN 32
+#endif
+#ifndef RT_PATH_BATCH
+#define RT_PATH_BATCH 512
+#endif
+enum { PH_NEW = 0, PH_TRAV = 1, PH_SHADE = 2, PH_IDLE = 3 };
+
+template <bool STATS>
+__global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
+                                                                              unsigned int* __restrict__ path_counter,
+                                                                              unsigned long long* __restrict__ stats, int n_cached,
+                                                                              int stack_entries, int chunk_k0, int chunk_S,
+                                                                              unsigned int n_paths) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
+    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+    __syncthreads();
+    const bool use_bvh = (P.flags & RT_F_BVH) != 0;
+    const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
+    Counters cn;
+    cn.clear();
+    [[maybe_unused]] const unsigned long long plife0 = RT_PROF_CLOCK();
+
+    // wave-uniform path source: paths [batch_next, batch_end) are not handed out yet
+    unsigned int batch_next = 0, batch_end = 0;
+    bool paths_left = true;
+    // lane state
+    int phase = PH_NEW;
+    unsigned int path = 0;
+    int bounce = 0;
+    f3 thr = mk(1.f, 1.f, 1.f);
+    float ri = 1.0f;
+    Rng rng;
+    rng.init(P.seed, 0, 0);
+    Trav t;
+    t.o = t.d = t.inv = t.hitPos = mk(0.f, 0.f, 0.f);
+    t.cur = RT_TRAV_DONE;
+    t.sp = 0;
+    t.hitTri = -1;
+    t.minD2 = 1e12f;
+
+    for (;;) {
+        const unsigned long long mNeed = __ballot(phase == PH_NEW || phase == PH_SHADE);
+        const unsigned long long mTrav = __ballot(phase == PH_TRAV);
+        if (__popcll(mNeed) >= RT_REGEN_MIN || mTrav == 0) {
+            if (mNeed == 0) break;  // every lane idle: no paths left
+            [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
+            RT_PROF_COUNT(cn, 3, 1);
+            if (phase == PH_NEW || phase == PH_SHADE) RT_PROF_LANE(cn, 4);
+            bool go = false;        // this lane holds a ray whose traversal starts in this pass
+            if (phase == PH_SHADE) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
+                const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
+                PathState ray;
+                ray.o = t.o;
+                ray.d = t.d;
+                ray.thr = thr;
+                ray.emission = mk(0.f, 0.f, 0.f);
+                ray.ri = ri;
+                ray.volDensity = 0.0f;
+                ray.volColor = mk(1.f, 1.f, 1.f);
+                f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
+                bool alive = true, handled = false;
+                if (spheres_on) {
+                    f3 sPos;
+                    const int hitSphere = trav_spheres(sc, t, sPos);
+                    if (hitSphere >= 0) {
+                        const float4 s0 = sc.spheres[2 * hitSphere];
+                        const f3 sNrm = normalize(sPos - mk(s0.x, s0.y, s0.z));
+                        const int mat = __float_as_int(sc.spheres[2 * hitSphere + 1].x);
+                        if (STATS) cn.hits++;
+                        shade_sphere<STATS>(sc, ray, sNrm, sPos, mat, rng, bb, cn);
+                        handled = true;  // `continue` at main.cu:343: no renormalise
+                    }
+                }
+                if (!handled) {
+                    if (t.hitTri >= 0) {
+                        if (STATS) cn.hits++;
+                        if (shade_triangle<STATS>(sc, ray, t.hitPos, t.hitTri, rng, bb, cn)) {  // main.cu:357-360
+                            e = ray.emission * ray.thr;
+                            alive = false;
+                        } else {
+                            ray.d = normalize_keep(ray.d);  // main.cu:361
+                        }
+                    } else {  // main.cu:374-387
+                        if ((P.flags & RT_F_SKYBOX) && P.env_w > 0) {
+                            const long long envI = env_index(ray.d, P.env_w, P.env_h);
+                            if (STATS) cn.texels++;
+                            e = fetch_texel(sc, envI) * ray.thr * P.bg_brightness;
+                        } else {
+                            e = ld3(P.bg) * ray.thr * P.bg_brightness;
+                        }
+                        alive = false;
+                    }
+                }
+                bounce++;
+                if (bounce >= P.max_bounces) alive = false;  // path exhausted: contributes 0
+                if (alive) {
+                    t.o = ray.o;
+                    t.d = ray.d;
+                    thr = ray.thr;
+                    ri = ray.ri;
+                    go = true;
+                } else {
+                    float* o = samples + 3 * (size_t)path;
+                    o[0] = e.x;
+                    o[1] = e.y;
+                    o[2] = e.z;
+                    phase = PH_NEW;
+                }
+            }
+            // lanes without a path take the next ones of the wave's batch
+            bool needpath = phase == PH_NEW;
+            int x = 0, y = 0;
+            unsigned long long m = __ballot(needpath);
+            while (m) {
+                if (batch_next >= batch_end) {
+                    if (!paths_left) break;
+                    unsigned int b = 0;
+                    if (lane == 0) b = atomicAdd(path_counter, (unsigned)RT_PATH_BATCH);
+                    batch_next = __builtin_amdgcn_readfirstlane(b);
+                    if (batch_next >= n_paths) { paths_left = false; batch_end = batch_next; break; }
+                    batch_end = min(batch_next + (unsigned)RT_PATH_BATCH, n_paths);
+                }
+                const unsigned int avail = batch_end - batch_next;
+                const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (needpath && rank < avail) {
+                    path = batch_next + rank;
+                    const unsigned int q = path >> 6, pi = path & 63u;
+                    const unsigned int tile = q / (unsigned)chunk_S, k = q - tile * (unsigned)chunk_S;
+                    const unsigned int ty = tile / (unsigned)P.tiles_x, tx = tile - ty * (unsigned)P.tiles_x;
+                    x = (int)(tx * 8 + (pi & 7));
+                    const int r = (int)(ty * 8 + (pi >> 3));
+                    if (x < P.width && r < P.rows) {  // (a path of a pixel outside the image is consumed and the lane asks again)
+                        y = row_to_y(P, r);
+                        rng.pixel = (uint32_t)(x + y * P.width);  // main.cu:171
+                        rng.sample = (uint32_t)(P.sample_begin + chunk_k0 + (int)k);
+                        needpath = false;
+                    }
+                }
+                batch_next += min(avail, (unsigned)__popcll(m));
+                m = __ballot(needpath);
+            }
+            if (phase == PH_NEW) {
+                if (needpath) {
+                    phase = PH_IDLE;
+                } else {  // camera sample (main.cu:178-217)
+                    camera_ray(P, x, y, rng, t.o, t.d);
+                    thr = mk(1.f, 1.f, 1.f);
+                    ri = 1.0f;
+                    bounce = 0;
+                    if (STATS) cn.paths++;
+                    if (P.max_bounces > 0) {
+                        go = true;
+                    } else {  // the bounce loop never runs: the sample contributes 0
+                        float* o = samples + 3 * (size_t)path;
+                        o[0] = 0.f;
+                        o[1] = 0.f;
+                        o[2] = 0.f;
+                    }
+                }
+            }
+            if (go) {  // main.cu:221-236
+                if (STATS) cn.rays++;
+                trav_begin(sc, t, t.o, t.d);
+                if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
+                phase = (t.cur == RT_TRAV_DONE) ? PH_SHADE : PH_TRAV;
+            }
+            RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
+        }
+        [[maybe_unused]] const unsigned long long pt0 = RT_PROF_CLOCK();
+        if (phase == PH_TRAV) {
+            RT_PROF_COUNT(cn, 0, 1);
+            RT_PROF_LANE(cn, 1);
+            trav_step<STATS>(sc, t, stk, cn, n_cached);
+            if (t.cur == RT_TRAV_DONE) phase = PH_SHADE;
+        }
+        RT_PROF_COUNT(cn, 2, RT_PROF_CLOCK() - pt0);
+    }
+
+    RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
+    if (STATS) {
+        uint32_t v[8] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            unsigned long long s = v[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&stats[i], s);
+        }
+#ifdef RT_CYCLE_PROF
+        for (int i = 0; i < 8; i++) {
+            unsigned long long s = cn.prof[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&stats[8 + i], s);
+        }
+#endif
+    }
+}
+
+// Adds the chunk's samples of every pixel, in sample order, to the accumulator (thread = pixel of a tile).
+__global__ void rt_sum_samples_kernel(const float* __restrict__ samples, float* __restrict__ accum, Params P, int chunk_S) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)P.n_tiles * 64) return;
+    const unsigned int tile = (unsigned int)(i >> 6), pi = (unsigned int)(i & 63);
+    const unsigned int ty = tile / (unsigned)P.tiles_x, tx = tile - ty * (unsigned)P.tiles_x;
+    const int x = (int)(tx * 8 + (pi & 7)), r = (int)(ty * 8 + (pi >> 3));
+    if (x >= P.width || r >= P.rows) return;
+    const float* s = samples + ((size_t)tile * chunk_S * 64 + pi) * 3;
+    f3 c = mk(0.f, 0.f, 0.f);
+    for (int k = 0; k < chunk_S; k++, s += 64 * 3) {
+        c.x += s[0];
+        c.y += s[1];
+        c.z += s[2];
+    }
+    float* a = accum + ((size_t)r * P.width + x) * 3;
+    a[0] += c.x;
+    a[1] += c.y;
+    a[2] += c.z;
 }
 
 // =============================================================================== wavefront pipeline
@@ -690,6 +942,8 @@ struct rt_context {
     int wf_slots = 0;
     int trace_lds_set = 0;   // dynamic-LDS limit already granted to the trace kernels
     int mega_lds_set = 0;
+    float* d_samples = nullptr;  // per-path radiance of the chunk in flight (path-parallel fused kernel), grow-only
+    size_t samples_floats = 0;
     std::vector<hipEvent_t> ev_pool;
     unsigned int* h_pinned = nullptr;
 };
@@ -833,7 +1087,7 @@ int rt_create(rt_context** out, int device_id) {
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipMalloc((void**)&c->d_tile_counter, 256) == hipSuccess &&
               hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void**)&c->d_stats, 8 * sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc((void**)&c->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         rt_destroy(c);
         return RT_ERR_DEVICE;
@@ -849,6 +1103,7 @@ void rt_destroy(rt_context* c) {
     free_scene(c);
     if (c->d_accum_own) (void)hipFree(c->d_accum_own);
     if (c->d_tile_counter) (void)hipFree(c->d_tile_counter);
+    if (c->d_samples) (void)hipFree(c->d_samples);
     if (c->d_wf) (void)hipFree(c->d_wf);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1125,29 +1380,100 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     c->mega_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
 
-int render_megakernel(rt_context* c, const Params& P, float* accum, bool want_stats) {
+// Lock-step fused kernel (one lane owns a pixel for the whole call).
+int render_lockstep(rt_context* c, const Params& P, float* accum, bool want_stats) {
     HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
     // persistent grid: ONE block of RT_MEGA_WAVES waves per CU (its register count allows no more), never more than the work
     const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES);
     int rc = set_mega_lds(c, tc);
     if (rc != RT_OK) return rc;
+    typedef void (*mega_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int);
+    const mega_fn kfn = want_stats ? rt_render_kernel<true> : rt_render_kernel<false>;
     int occ = 0;
-    const void* kfn = want_stats ? (const void*)rt_render_kernel<true> : (const void*)rt_render_kernel<false>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     const int want_blocks = (P.n_tiles + RT_MEGA_WAVES - 1) / RT_MEGA_WAVES;
     const int blocks = std::max(1, std::min(c->num_cus * occ, want_blocks));
-    if (want_stats)
-        hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, accum,
-                           c->d_tile_counter, c->d_stats, tc.n_cached, tc.stack_entries);
-    else
-        hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, accum,
-                           c->d_tile_counter, c->d_stats, tc.n_cached, tc.stack_entries);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, accum, c->d_tile_counter,
+                       c->d_stats, tc.n_cached, tc.stack_entries);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
+}
+
+// Path-parallel fused kernel: the call's samples in chunks of S; per chunk one persistent launch that
+// writes one radiance per path, and one pass that adds them to the accumulator in sample order.
+int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, bool profile, rt_render_stats* out) {
+    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES);
+    int rc = set_mega_lds(c, tc);
+    if (rc != RT_OK) return rc;
+    const size_t slots = (size_t)P.n_tiles * 64;  // pixels incl. the padding of edge tiles
+    size_t budget = (size_t)8 << 30;              // bytes of per-path radiance kept in flight (HBM is 288 GB)
+    if (const char* e = getenv("RT_SAMPLE_BUF_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;  // experiments only
+    long long S = std::min<long long>(P.sample_count, std::max<long long>(1, (long long)(budget / (slots * 12))));
+    S = std::min<long long>(S, (long long)(0x7fffffffu / slots));  // 32-bit path counter
+    if (S < 1) return set_err(c, RT_ERR_LIMIT, "image too large for the path-parallel kernel");
+    while (c->samples_floats < slots * (size_t)S * 3) {
+        if (c->d_samples) (void)hipFree(c->d_samples);
+        c->d_samples = nullptr;
+        c->samples_floats = 0;
+        if (hipMalloc((void**)&c->d_samples, slots * (size_t)S * 12) == hipSuccess) {
+            c->samples_floats = slots * (size_t)S * 3;
+            break;
+        }
+        (void)hipGetLastError();
+        if (S == 1) return set_err(c, RT_ERR_NOMEM, "no device memory for the per-path radiance buffer");
+        S = (S + 1) / 2;
+    }
+    typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
+    const paths_fn kfn = want_stats ? rt_render_paths_kernel<true> : rt_render_paths_kernel<false>;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
+    size_t ev_used = 0;
+    for (long long k0 = 0; k0 < P.sample_count; k0 += S) {
+        const int s = (int)std::min<long long>(S, P.sample_count - k0);
+        const unsigned int n_paths = (unsigned int)(slots * (size_t)s);
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+        const long long want_blocks = ((long long)n_paths + 64 * RT_MEGA_WAVES - 1) / (64 * RT_MEGA_WAVES);
+        const int blocks = (int)std::max<long long>(1, std::min<long long>((long long)c->num_cus * occ, want_blocks));
+        const bool timed = profile && ev_used + 2 <= 4096;
+        if (timed) {
+            while (c->ev_pool.size() < ev_used + 2) {
+                hipEvent_t e;
+                HIP_TRY(c, hipEventCreate(&e));
+                c->ev_pool.push_back(e);
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used], c->stream));
+        }
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, c->d_samples, c->d_tile_counter,
+                           c->d_stats, tc.n_cached, tc.stack_entries, (int)k0, s, n_paths);
+        if (timed) {
+            HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
+            ev_used += 2;
+        }
+        hipLaunchKernelGGL(rt_sum_samples_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c->stream, c->d_samples, accum, P, s);
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (out && profile && ev_used) {  // RT_F_PROFILE: summed duration of the path kernel's launches alone
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        double sum = 0.0;
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
+            sum += ms;
+        }
+        out->trace_ms = sum;
+        out->trace_launches = (uint32_t)(ev_used / 2);
+    }
+    return RT_OK;
+}
+
+int render_megakernel(rt_context* c, const Params& P, float* accum, bool want_stats, bool profile, rt_render_stats* out) {
+    return (P.flags & RT_F_LOCKSTEP) ? render_lockstep(c, P, accum, want_stats) : render_paths(c, P, accum, want_stats, profile, out);
 }
 
 // Wavefront loop: logic -> trace -> logic -> ... until no slot emits a ray.
@@ -1243,11 +1569,11 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
     const bool want_stats = (P.flags & RT_F_STATS) != 0;
     const bool profile = (P.flags & RT_F_PROFILE) != 0;
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
     const bool work = P.n_tiles > 0 && P.sample_count > 0;
     if (work) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (!(P.flags & RT_F_WAVEFRONT)) rc = render_megakernel(c, P, accum, want_stats);
+        if (!(P.flags & RT_F_WAVEFRONT)) rc = render_megakernel(c, P, accum, want_stats, profile, stats);
         else rc = render_wavefront(c, P, accum, want_stats, profile, stats);
         if (rc != RT_OK) return rc;
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1261,8 +1587,14 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
             stats->kernel_ms = ms;
         }
         if (want_stats) {
-            unsigned long long h[8];
+            unsigned long long h[16];
             HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef RT_CYCLE_PROF
+            fprintf(stderr, "[rt prof] trav: %llu wave-iterations, %llu lane-steps (%.1f lanes/iteration), %llu cycles (%.0f per iteration); "
+                            "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass); wave lifetimes %llu cycles; kernel %.3f ms\n",
+                    h[8], h[9], h[8] ? (double)h[9] / h[8] : 0.0, h[10], h[8] ? (double)h[10] / h[8] : 0.0, h[11], h[12],
+                    h[11] ? (double)h[12] / h[11] : 0.0, h[13], h[11] ? (double)h[13] / h[11] : 0.0, h[14], stats->kernel_ms);
+#endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
         }

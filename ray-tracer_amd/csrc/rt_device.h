@@ -162,8 +162,26 @@ __device__ __forceinline__ float gauss(uint32_t a, uint32_t b) {  // normal from
 // ------------------------------------------------------------------ counters
 struct Counters {
     uint32_t paths, rays, inner, leaf, tri, hits, texels, lights;
-    __device__ __forceinline__ void clear() { paths = rays = inner = leaf = tri = hits = texels = lights = 0; }
+#ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
+    unsigned long long prof[8];  // 0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
+#endif
+    __device__ __forceinline__ void clear() {
+        paths = rays = inner = leaf = tri = hits = texels = lights = 0;
+#ifdef RT_CYCLE_PROF
+        for (int i = 0; i < 8; i++) prof[i] = 0;
+#endif
+    }
 };
+#ifdef RT_CYCLE_PROF
+__device__ __forceinline__ bool prof_leader() { return (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1; }
+#define RT_PROF_COUNT(cn, i, v) do { if (STATS && prof_leader()) (cn).prof[i] += (v); } while (0)
+#define RT_PROF_LANE(cn, i) do { if (STATS) (cn).prof[i] += 1; } while (0)
+#define RT_PROF_CLOCK() (STATS ? (unsigned long long)clock64() : 0ull)
+#else
+#define RT_PROF_COUNT(cn, i, v) do {} while (0)
+#define RT_PROF_LANE(cn, i) do {} while (0)
+#define RT_PROF_CLOCK() 0ull
+#endif
 
 // ------------------------------------------------------------------ intersection
 
@@ -349,10 +367,16 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
     }
     float4 q0, q1, q2, q3;
     if (t.cur < n_cached) {
-        q0 = rt_lds[t.cur];
-        q1 = rt_lds[n_cached + t.cur];
-        q2 = rt_lds[2 * n_cached + t.cur];
-        q3 = rt_lds[3 * n_cached + t.cur];
+        // volatile: keeps these four ds_read_b128 apart from the global loads below (without it the
+        // compiler merges both sides into FLAT loads through a selected generic pointer, split into
+        // eleven narrower loads per step)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const volatile __attribute__((address_space(3))) v4f* c = (const volatile __attribute__((address_space(3))) v4f*)rt_lds;
+        const v4f a0 = c[t.cur], a1 = c[n_cached + t.cur], a2 = c[2 * n_cached + t.cur], a3 = c[3 * n_cached + t.cur];
+        q0 = make_float4(a0.x, a0.y, a0.z, a0.w);
+        q1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+        q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+        q3 = make_float4(a3.x, a3.y, a3.z, a3.w);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
@@ -436,7 +460,11 @@ __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool 
         while (t.cur >= sc.n_inner || t.cur == RT_TRAV_EMPTY) trav_step<STATS>(sc, t, stk, cn, n_cached);
     }
 #else
-    while (t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn, n_cached);
+    while (t.cur != RT_TRAV_DONE) {
+        RT_PROF_COUNT(cn, 0, 1);
+        RT_PROF_LANE(cn, 1);
+        trav_step<STATS>(sc, t, stk, cn, n_cached);
+    }
 #endif
     hitTri = t.hitTri;
     minD2 = t.minD2;

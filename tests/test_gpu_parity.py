@@ -84,7 +84,7 @@ def image_metrics(a, b):
     return mean_rel, rel_rmse
 
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
 @pytest.mark.parametrize("name,size,spp,bounces", [
     ("scene_cornellbox.txt", 256, 16, 4),   # BASELINE config 1 (reduced image size elsewhere)
     ("scene.txt", 128, 16, 6),
@@ -93,7 +93,7 @@ def image_metrics(a, b):
 ])
 def test_image_matches_oracle_same_rng(ob, rt, gpu, scenes, name, size, spp, bounces, mode):
     sc = scenes(name)
-    flags = rt.F_DEFAULT | rt.F_STATS | (rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT)
+    flags = rt.F_DEFAULT | rt.F_STATS | rt.MODE_FLAGS[mode]
     p = rt.default_params(sc.camera, spp=spp, width=size, height=size, max_bounces=bounces, flags=flags)
     gpu.upload(sc)
     gpu.reset()

@@ -185,7 +185,7 @@ def test_shade_every_material_type_bit_exact(ob, rt, gpu):
 
 # ---- golden fixtures ------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
 @pytest.mark.parametrize("name", ["scene_cornellbox", "scene", "scene2", "scene2_is"])
 def test_gpu_matches_committed_golden(rt, gpu, scenes, name, mode):
     g = np.load(os.path.join(GOLD, name + ".npz"))
@@ -198,7 +198,7 @@ def test_gpu_matches_committed_golden(rt, gpu, scenes, name, mode):
     assert np.all(np.abs(nrm[hit] - g["normal"][hit]) <= 1e-5)               # normals: 1e-5
     assert np.array_equal(cnt, g["counts"])
     size, spp, bounces = int(g["img_size"]), int(g["img_spp"]), int(g["img_bounces"])
-    flags = rt.F_DEFAULT | rt.F_STATS | (rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT)
+    flags = rt.F_DEFAULT | rt.F_STATS | rt.MODE_FLAGS[mode]
     p = rt.default_params(sc.camera, spp=spp, width=size, height=size, max_bounces=bounces, flags=flags)
     gpu.reset()
     st = gpu.render(p)
@@ -212,7 +212,7 @@ def test_gpu_matches_committed_golden(rt, gpu, scenes, name, mode):
 
 # ---- options and edge cases --------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
 def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
     txt = ("SET_OUTPUT_WIDTH 48\nSET_OUTPUT_HEIGHT 40\nSET_FOCAL_LENGTH 0.5\nSET_APERTURE_RADIUS 0.05\n\n"
            "DEF_IMAGE env\nPATH cape_hill_1k.hdr\n\nDEF_IMAGE earth\nPATH earth.ppm\n\nDEF_MODEL m\nPATH plane.obj\n\n"
@@ -225,7 +225,7 @@ def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
     f.write_text(txt)
     sc = rt.Scene.load(str(f), enable_spheres=True)
     gpu.upload(sc)
-    m = rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT
+    m = rt.MODE_FLAGS[mode]
     for flags in [rt.F_DEFAULT | rt.F_SPHERES, rt.F_BVH | rt.F_SPHERES, rt.F_SKYBOX | rt.F_ANTIALIAS | rt.F_SPHERES,
                   rt.F_DEFAULT]:
         p = rt.default_params(sc.camera, spp=4, flags=flags | rt.F_STATS | m)
@@ -236,11 +236,11 @@ def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
         assert (st.rays, st.tri_tests, st.hits, st.texel_fetches) == (ost.rays, ost.tri_tests, ost.hits, ost.texel_fetches)
 
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
 def test_motion_blur_and_ragged_image_sizes(ob, rt, gpu, scenes, mode):
     sc = scenes("scene.txt")
     gpu.upload(sc)
-    m = rt.F_MEGAKERNEL if mode == "megakernel" else rt.F_WAVEFRONT
+    m = rt.MODE_FLAGS[mode]
     for (w, h) in [(1, 1), (7, 3), (65, 9), (100, 33)]:
         p = rt.default_params(sc.camera, spp=3, width=w, height=h, flags=rt.F_DEFAULT | m)
         p.cam.vel[:] = [0.2, 0.1, 0.0]
@@ -255,7 +255,7 @@ def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
     mt = rt.Material(); mt.type = 3; mt.color = 0xFFFFFF; mt.image_offset[:] = [-1, -1, -1]
     sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mt])
     gpu.upload(sc)
-    for m in (rt.F_MEGAKERNEL, rt.F_WAVEFRONT):
+    for m in rt.MODE_FLAGS.values():
         p = rt.default_params(sc.camera, spp=3, width=20, height=10, flags=rt.F_DEFAULT | rt.F_STATS | m)
         gpu.reset()
         st = gpu.render(p)
@@ -263,7 +263,7 @@ def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
         assert st.rays == st.paths == 600
     sc = scenes("scene_cornellbox.txt")
     gpu.upload(sc)
-    for m in (rt.F_MEGAKERNEL, rt.F_WAVEFRONT):
+    for m in rt.MODE_FLAGS.values():
         p = rt.default_params(sc.camera, spp=2, width=16, height=16, max_bounces=0, flags=rt.F_DEFAULT | rt.F_STATS | m)
         gpu.reset()
         st = gpu.render(p)
