@@ -209,12 +209,18 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 // Path index p within a chunk of S samples: p = ((tile * S + k) * 64 + pixel-in-tile), so the 64
 // lanes of a wave mostly hold neighbouring pixels of one sample.
 #ifndef RT_REGEN_MIN
-#define RT_REGEN_MIN 32
+#define RT_REGEN_MIN 40
+#endif
+#ifndef RT_TRI_MIN
+#define RT_TRI_MIN 16  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
 #endif
-enum { PH_NEW = 0, PH_TRAV = 1, PH_SHADE = 2, PH_IDLE = 3 };
+// A lane's phase lives in Trav::cur: >= 0 traversing (inner node below n_inner, else a leaf), RT_TRAV_DONE =
+// closest hit known, vertex pending; RT_LANE_NEW = wants a path; RT_LANE_IDLE = no paths left.
+#define RT_LANE_NEW (-2)
+#define RT_LANE_IDLE (-3)
 
 template <bool STATS>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
@@ -237,7 +243,6 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     unsigned int batch_next = 0, batch_end = 0;
     bool paths_left = true;
     // lane state
-    int phase = PH_NEW;
     unsigned int path = 0;
     int bounce = 0;
     f3 thr = mk(1.f, 1.f, 1.f);
@@ -246,21 +251,21 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     rng.init(P.seed, 0, 0);
     Trav t;
     t.o = t.d = t.inv = t.hitPos = mk(0.f, 0.f, 0.f);
-    t.cur = RT_TRAV_DONE;
+    t.cur = RT_LANE_NEW;
     t.sp = 0;
     t.hitTri = -1;
     t.minD2 = 1e12f;
 
     for (;;) {
-        const unsigned long long mNeed = __ballot(phase == PH_NEW || phase == PH_SHADE);
-        const unsigned long long mTrav = __ballot(phase == PH_TRAV);
+        const unsigned long long mNeed = __ballot((unsigned)(t.cur + 2) < 2u);  // RT_TRAV_DONE or RT_LANE_NEW
+        const unsigned long long mTrav = __ballot(t.cur >= 0);
         if (__popcll(mNeed) >= RT_REGEN_MIN || mTrav == 0) {
             if (mNeed == 0) break;  // every lane idle: no paths left
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
-            if (phase == PH_NEW || phase == PH_SHADE) RT_PROF_LANE(cn, 4);
+            if ((unsigned)(t.cur + 2) < 2u) RT_PROF_LANE(cn, 4);
             bool go = false;        // this lane holds a ray whose traversal starts in this pass
-            if (phase == PH_SHADE) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
+            if (t.cur == RT_TRAV_DONE) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
                 const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
                 PathState ray;
                 ray.o = t.o;
@@ -317,11 +322,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     o[0] = e.x;
                     o[1] = e.y;
                     o[2] = e.z;
-                    phase = PH_NEW;
+                    t.cur = RT_LANE_NEW;
                 }
             }
             // lanes without a path take the next ones of the wave's batch
-            bool needpath = phase == PH_NEW;
+            bool needpath = t.cur == RT_LANE_NEW;
             int x = 0, y = 0;
             unsigned long long m = __ballot(needpath);
             while (m) {
@@ -352,9 +357,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 batch_next += min(avail, (unsigned)__popcll(m));
                 m = __ballot(needpath);
             }
-            if (phase == PH_NEW) {
+            if (t.cur == RT_LANE_NEW) {
                 if (needpath) {
-                    phase = PH_IDLE;
+                    t.cur = RT_LANE_IDLE;
                 } else {  // camera sample (main.cu:178-217)
                     camera_ray(P, x, y, rng, t.o, t.d);
                     thr = mk(1.f, 1.f, 1.f);
@@ -375,17 +380,36 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 if (STATS) cn.rays++;
                 trav_begin(sc, t, t.o, t.d);
                 if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
-                phase = (t.cur == RT_TRAV_DONE) ? PH_SHADE : PH_TRAV;
             }
             RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
         }
         [[maybe_unused]] const unsigned long long pt0 = RT_PROF_CLOCK();
-        if (phase == PH_TRAV) {
+#if RT_TRI_MIN > 0
+        // one KIND of step per iteration, by vote: triangle tests when enough lanes wait at a leaf (or none is at an
+        // inner node), inner-node visits otherwise -- the iteration executes the code of that kind only
+        const bool at_inner = trav_at_inner(sc, t);
+        const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
+        const unsigned long long mLeaf = __ballot(at_leaf);
+        if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
+            if (at_leaf) {
+                RT_PROF_COUNT(cn, 0, 1);
+                RT_PROF_LANE(cn, 1);
+                trav_step_leaf<STATS>(sc, t, stk, cn);
+            }
+        } else {
+            if (at_inner) {
+                RT_PROF_COUNT(cn, 0, 1);
+                RT_PROF_LANE(cn, 1);
+                trav_step_inner<STATS>(sc, t, stk, cn, n_cached);
+            }
+        }
+#else
+        if (t.cur >= 0) {
             RT_PROF_COUNT(cn, 0, 1);
             RT_PROF_LANE(cn, 1);
             trav_step<STATS>(sc, t, stk, cn, n_cached);
-            if (t.cur == RT_TRAV_DONE) phase = PH_SHADE;
         }
+#endif
         RT_PROF_COUNT(cn, 2, RT_PROF_CLOCK() - pt0);
     }
 

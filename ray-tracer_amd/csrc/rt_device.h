@@ -320,7 +320,7 @@ struct Attractor {
 extern __shared__ float4 rt_lds[];  // dynamic LDS: [4 * n_cached node pieces][per-lane stacks]
 
 #define RT_TRAV_DONE (-1)   // query finished
-#define RT_TRAV_EMPTY (-2)  // a leaf without triangles (visited, nothing to test)
+#define RT_TRAV_EMPTY 0x7ffffff0  // a leaf without triangles (visited, nothing to test); sorts after every item index
 
 // Per-lane traversal state of one closest-hit query.
 struct Trav {
@@ -358,6 +358,75 @@ __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
 // n_cached: the first n_cached inner items (the top of the tree in BFS order) are held in the
 // dynamic LDS array as four piece arrays rt_lds[k * n_cached + node]: a divergent 16-byte request costs the
 // vector-memory pipeline a full cycle each, the LDS serves them several times faster.
+// The node cache: the first n_cached inner items (the top of the tree in BFS order) live in the dynamic
+// LDS array as four piece arrays rt_lds[k * n_cached + node] -- a divergent 16-byte request costs the
+// vector-memory pipeline a full cycle per lane, the LDS serves them several times faster.
+// volatile + explicit address space: keeps these four ds_read_b128 apart from global loads (without it
+// the compiler merges both sides into FLAT loads through a selected generic pointer, split into eleven
+// narrower loads per step).
+__device__ __forceinline__ void load_cached_item(int item, int n_cached, float4& q0, float4& q1, float4& q2, float4& q3) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const volatile __attribute__((address_space(3))) v4f* c = (const volatile __attribute__((address_space(3))) v4f*)rt_lds;
+    const v4f a0 = c[item], a1 = c[n_cached + item], a2 = c[2 * n_cached + item], a3 = c[3 * n_cached + item];
+    q0 = make_float4(a0.x, a0.y, a0.z, a0.w);
+    q1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+    q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+    q3 = make_float4(a3.x, a3.y, a3.z, a3.w);
+}
+
+// AABBIntersectDistance again, without branches, for the traversal loop.  Same values as aabb_distance:
+// a = mn - o and b = mx - o are the differences the slab test forms anyway, and "o inside the box"
+// (mn <= o <= mx on every axis) is "every a <= 0 and every b >= 0" because an f32 difference has the
+// sign of the exact one (denormals are kept); box bounds and ray origins are never NaN.  tmin cannot be
+// negative (it starts at 0 and only grows), so the reference's `tmin < 0` exit is dead.
+__device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {
+    const f3 a = mn - o, b = mx - o;
+    const bool inside = fmaxf(fmaxf(a.x, a.y), a.z) <= 0.0f && fminf(fminf(b.x, b.y), b.z) >= 0.0f;
+    const f3 t1 = a * inv, t2 = b * inv;
+    float tmin = fmaxf(0.0f, fminf(t1.x, t2.x));
+    float tmax = fminf(1e13f, fmaxf(t1.x, t2.x));
+    tmin = fmaxf(tmin, fminf(t1.y, t2.y));
+    tmax = fminf(tmax, fmaxf(t1.y, t2.y));
+    tmin = fmaxf(tmin, fminf(t1.z, t2.z));
+    tmax = fminf(tmax, fmaxf(t1.z, t2.z));
+    const float r = (tmax < tmin) ? 1e13f : tmin;
+    return inside ? 0.0f : r;
+}
+
+// Inner-node visit (main.cu:265-279) on the fetched item.
+template <bool STATS>
+__device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, float4 q0, float4 q1, float4 q2, float4 q3) {
+    if (STATS) cn.inner++;
+    float dA = aabb_distance_nb(t.o, t.inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
+    float dB = aabb_distance_nb(t.o, t.inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+    dA = dA * dA;
+    dB = dB * dB;
+    const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
+    const bool aNear = dA < dB;
+    const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
+    const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
+    if (dFar < t.minD2) { stk[t.sp * 64] = eFar; t.sp++; }
+    if (dNear < t.minD2) t.cur = eNear;
+    else trav_pop(t, stk);
+}
+
+// One triangle test of the current leaf (main.cu:249-264) on the fetched item.
+template <bool STATS>
+__device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, float4 q0, float4 q1, float4 q2) {
+    const int flags = __float_as_int(q2.y);
+    if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
+    f3 pos;
+    if (ray_triangle(t.o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), pos)) {
+        const float nd = len2(pos - t.o);
+        if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = t.cur - sc.n_inner; }
+    }
+    if (flags & 1) trav_pop(t, stk);
+    else t.cur++;
+}
+
+// ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit or one
+// triangle test of the current leaf.  All lanes of the wave share the four item loads, whatever kind
+// of item each of them holds.
 template <bool STATS>
 __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached = 0) {
     if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
@@ -367,44 +436,40 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
     }
     float4 q0, q1, q2, q3;
     if (t.cur < n_cached) {
-        // volatile: keeps these four ds_read_b128 apart from the global loads below (without it the
-        // compiler merges both sides into FLAT loads through a selected generic pointer, split into
-        // eleven narrower loads per step)
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const volatile __attribute__((address_space(3))) v4f* c = (const volatile __attribute__((address_space(3))) v4f*)rt_lds;
-        const v4f a0 = c[t.cur], a1 = c[n_cached + t.cur], a2 = c[2 * n_cached + t.cur], a3 = c[3 * n_cached + t.cur];
-        q0 = make_float4(a0.x, a0.y, a0.z, a0.w);
-        q1 = make_float4(a1.x, a1.y, a1.z, a1.w);
-        q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
-        q3 = make_float4(a3.x, a3.y, a3.z, a3.w);
+        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
-    if (t.cur < sc.n_inner) {
-        if (STATS) cn.inner++;
-        float dA = aabb_distance(t.o, t.inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-        float dB = aabb_distance(t.o, t.inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
-        dA = dA * dA;
-        dB = dB * dB;
-        const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
-        const bool aNear = dA < dB;
-        const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
-        const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
-        if (dFar < t.minD2) { stk[t.sp * 64] = eFar; t.sp++; }
-        if (dNear < t.minD2) t.cur = eNear;
-        else trav_pop(t, stk);
+    if (t.cur < sc.n_inner) visit_inner<STATS>(t, stk, cn, q0, q1, q2, q3);
+    else visit_triangle<STATS>(sc, t, stk, cn, q0, q1, q2);
+}
+
+// The two kinds of step on their own, for schedulers that run them in separate wave-uniform phases
+// (rt_render_paths_kernel): an iteration then executes the code of one kind only.
+__device__ __forceinline__ bool trav_at_inner(const Scene& sc, const Trav& t) { return (unsigned)t.cur < (unsigned)sc.n_inner; }
+
+template <bool STATS>
+__device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached) {  // trav_at_inner(t)
+    float4 q0, q1, q2, q3;
+    if (t.cur < n_cached) {
+        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
-        const int flags = __float_as_int(q2.y);
-        if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
-        f3 pos;
-        if (ray_triangle(t.o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), pos)) {
-            const float nd = len2(pos - t.o);
-            if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = t.cur - sc.n_inner; }
-        }
-        if (flags & 1) trav_pop(t, stk);
-        else t.cur++;
+        const float4* w = sc.items + 4 * (size_t)t.cur;
+        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
+    visit_inner<STATS>(t, stk, cn, q0, q1, q2, q3);
+}
+
+template <bool STATS>
+__device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn) {  // a triangle or RT_TRAV_EMPTY
+    if (t.cur == RT_TRAV_EMPTY) {
+        if (STATS) cn.leaf++;
+        trav_pop(t, stk);
+        return;
+    }
+    const float4* w = sc.items + 4 * (size_t)t.cur;
+    visit_triangle<STATS>(sc, t, stk, cn, w[0], w[1], w[2]);
 }
 
 // ENABLE_BVH false, main.cu:285-301
