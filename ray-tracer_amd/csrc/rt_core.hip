@@ -250,7 +250,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     Rng rng;
     rng.init(P.seed, 0, 0);
     Trav t;
-    t.o = t.d = t.inv = t.hitPos = mk(0.f, 0.f, 0.f);
+    t.oxy = t.ixy = (v2f){0.f, 0.f};
+    t.oz = t.iz = 0.f;
+    t.d = mk(0.f, 0.f, 0.f);
+    t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
+    f3 ro = mk(0.f, 0.f, 0.f);  // origin of the ray that starts in the current vertex pass
     t.cur = RT_LANE_NEW;
     t.sp = 0;
     t.hitTri = -1;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (t.cur == RT_TRAV_DONE) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
                 const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
                 PathState ray;
-                ray.o = t.o;
+                ray.o = t.o();
                 ray.d = t.d;
                 ray.thr = thr;
                 ray.emission = mk(0.f, 0.f, 0.f);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 if (!handled) {
                     if (t.hitTri >= 0) {
                         if (STATS) cn.hits++;
-                        if (shade_triangle<STATS>(sc, ray, t.hitPos, t.hitTri, rng, bb, cn)) {  // main.cu:357-360
+                        if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn)) {  // main.cu:357-360
                             e = ray.emission * ray.thr;
                             alive = false;
                         } else {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 bounce++;
                 if (bounce >= P.max_bounces) alive = false;  // path exhausted: contributes 0
                 if (alive) {
-                    t.o = ray.o;
+                    ro = ray.o;
                     t.d = ray.d;
                     thr = ray.thr;
                     ri = ray.ri;
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     t.cur = RT_LANE_NEW;
                 }
             }
+            RT_PROF_COUNT(cn, 7, RT_PROF_CLOCK() - pc0);
             // lanes without a path take the next ones of the wave's batch
             bool needpath = t.cur == RT_LANE_NEW;
             int x = 0, y = 0;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 if (needpath) {
                     t.cur = RT_LANE_IDLE;
                 } else {  // camera sample (main.cu:178-217)
-                    camera_ray(P, x, y, rng, t.o, t.d);
+                    camera_ray(P, x, y, rng, ro, t.d);
                     thr = mk(1.f, 1.f, 1.f);
                     ri = 1.0f;
                     bounce = 0;
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             }
             if (go) {  // main.cu:221-236
                 if (STATS) cn.rays++;
-                trav_begin(sc, t, t.o, t.d);
+                trav_begin(sc, t, ro, t.d);
                 if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
             }
             RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
@@ -729,12 +734,13 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
         if (has && t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn, n_cached);
         if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
             int tri = t.hitTri;
+            f3 hp = tri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
             if (spheres_on) {
                 f3 sPos;
                 const int si = trav_spheres(sc, t, sPos);
-                if (si >= 0) { tri = -2 - si; t.hitPos = sPos; }
+                if (si >= 0) { tri = -2 - si; hp = sPos; }
             }
-            hits[slot] = make_float4(t.hitPos.x, t.hitPos.y, t.hitPos.z, __int_as_float(tri));
+            hits[slot] = make_float4(hp.x, hp.y, hp.z, __int_as_float(tri));
             if (STATS) {
                 if (counts) { counts[slot * 3] = (int)cn.inner; counts[slot * 3 + 1] = (int)cn.leaf; counts[slot * 3 + 2] = (int)cn.tri; }
                 tot.inner += cn.inner; tot.leaf += cn.leaf; tot.tri += cn.tri;
@@ -1231,10 +1237,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             float* w = &items[(size_t)inner_index[i] * 16];
             const rt_bvh_node& A = s->nodes[n.child_a];
             const rt_bvh_node& B = s->nodes[n.child_b];
-            w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_min[2];
-            w[3] = A.bbox_max[0]; w[4] = A.bbox_max[1]; w[5] = A.bbox_max[2];
-            w[6] = B.bbox_min[0]; w[7] = B.bbox_min[1]; w[8] = B.bbox_min[2];
-            w[9] = B.bbox_max[0]; w[10] = B.bbox_max[1]; w[11] = B.bbox_max[2];
+            w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_max[0]; w[3] = A.bbox_max[1];
+            w[4] = B.bbox_min[0]; w[5] = B.bbox_min[1]; w[6] = B.bbox_max[0]; w[7] = B.bbox_max[1];
+            w[8] = A.bbox_min[2]; w[9] = A.bbox_max[2]; w[10] = B.bbox_min[2]; w[11] = B.bbox_max[2];
             w[12] = i2f(entry_of(n.child_a));
             w[13] = i2f(entry_of(n.child_b));
             w[14] = i2f(i);
@@ -1615,9 +1620,9 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
             HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
 #ifdef RT_CYCLE_PROF
             fprintf(stderr, "[rt prof] trav: %llu wave-iterations, %llu lane-steps (%.1f lanes/iteration), %llu cycles (%.0f per iteration); "
-                            "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass); wave lifetimes %llu cycles; kernel %.3f ms\n",
+                            "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass)(shading part %.0f); wave lifetimes %llu cycles; kernel %.3f ms\n",
                     h[8], h[9], h[8] ? (double)h[9] / h[8] : 0.0, h[10], h[8] ? (double)h[10] / h[8] : 0.0, h[11], h[12],
-                    h[11] ? (double)h[12] / h[11] : 0.0, h[13], h[11] ? (double)h[13] / h[11] : 0.0, h[14], stats->kernel_ms);
+                    h[11] ? (double)h[12] / h[11] : 0.0, h[13], h[11] ? (double)h[13] / h[11] : 0.0, h[11] ? (double)h[15] / h[11] : 0.0, h[14], stats->kernel_ms);
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];

@@ -26,9 +26,9 @@ namespace rtd {
 // items [n_inner, n_inner + n_tris) the triangles in the reference's (leaf-contiguous) order.
 //   inner item: both child boxes + both child entries (one 64-B fetch per inner visit instead
 //               of the reference's two 40-B child fetches, main.cu:268-269)
-//     q0 = (A.min.x, A.min.y, A.min.z, A.max.x)
-//     q1 = (A.max.y, A.max.z, B.min.x, B.min.y)
-//     q2 = (B.min.z, B.max.x, B.max.y, B.max.z)
+//     q0 = (A.min.x, A.min.y, A.max.x, A.max.y)      x/y pairs and z pairs: the slab differences and
+//     q1 = (B.min.x, B.min.y, B.max.x, B.max.y)      products run as packed two-float operations
+//     q2 = (A.min.z, A.max.z, B.min.z, B.max.z)
 //     q3 = (entryA, entryB, refNodeId, 0)            as int bits
 //     entry = item index of the child (inner node, or FIRST triangle of a leaf child),
 //             RT_TRAV_EMPTY for a leaf without triangles
@@ -185,8 +185,9 @@ __device__ __forceinline__ bool prof_leader() { return (threadIdx.x & 63) == __f
 
 // ------------------------------------------------------------------ intersection
 
-// rayTriangleIntersect, main.cu:41-70, on the pre-subtracted edges.
-__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, f3& outPos) {
+// rayTriangleIntersect, main.cu:41-70, on the pre-subtracted edges.  Yields the ray parameter; the hit
+// position is o + d * t (main.cu:66).
+__device__ __forceinline__ bool ray_triangle_t(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& outT) {
     const float epsilon = 1e-9f;
     const f3 p = cross(d, e2);
     const float det = dot(e1, p);
@@ -200,10 +201,16 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, f3
     if (v < 0.0f || u + v > 1.0f) return false;
     const float t = inv_det * dot(e2, q);
     if (t > epsilon) {
-        outPos = o + d * t;
+        outT = t;
         return true;
     }
     return false;
+}
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 v0, f3 e1, f3 e2, f3& outPos) {
+    float t;
+    if (!ray_triangle_t(o, d, v0, e1, e2, t)) return false;
+    outPos = o + d * t;
+    return true;
 }
 
 // AABBIntersectDistance, main.cu:73-117, with 1/dir hoisted out (same value).
@@ -322,28 +329,40 @@ extern __shared__ float4 rt_lds[];  // dynamic LDS: [4 * n_cached node pieces][p
 #define RT_TRAV_DONE (-1)   // query finished
 #define RT_TRAV_EMPTY 0x7ffffff0  // a leaf without triangles (visited, nothing to test); sorts after every item index
 
-// Per-lane traversal state of one closest-hit query.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Per-lane traversal state of one closest-hit query.  Origin and 1/direction are kept as an (x, y) pair
+// and z, the shape the packed box test consumes.
 struct Trav {
-    f3 o, d, inv;
+    v2f oxy, ixy;
+    float oz, iz;
+    f3 d;
+    __device__ __forceinline__ f3 o() const { return mk(oxy.x, oxy.y, oz); }
+    __device__ __forceinline__ f3 inv() const { return mk(ixy.x, ixy.y, iz); }
     int cur;      // item to visit next (inner node or triangle), RT_TRAV_EMPTY, or RT_TRAV_DONE
     int sp;       // entries on this lane's LDS stack
     int hitTri;   // triangle id (hitTriIndex / 25) or -1
     float minD2;  // minDistSqr, main.cu:223
-    f3 hitPos;
+    float hitT;   // ray parameter of the closest hit: its position o + d * hitT is formed again when the query is
+                  // over (same operands, same operations as main.cu:66 -> same bits) instead of being carried along
+    __device__ __forceinline__ f3 hit_pos() const { return o() + d * hitT; }
+    __device__ __forceinline__ void set_hit(float ht, f3) { hitT = ht; }
 };
 
 // main.cu:221-236: reset the query and test the root box once.
 __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d) {
-    t.o = o;
+    t.oxy = (v2f){o.x, o.y};
+    t.oz = o.z;
     t.d = d;
-    t.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    t.ixy = (v2f){1.0f / d.x, 1.0f / d.y};
+    t.iz = 1.0f / d.z;
     t.sp = 0;
     t.hitTri = -1;
     t.minD2 = 1e12f;
-    t.hitPos = mk(0.f, 0.f, 0.f);
+    t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
     // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
     // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
-    t.cur = (sc.has_root && aabb_distance(o, t.inv, ld3(sc.root_min), ld3(sc.root_max)) <= 1e12f) ? sc.root_entry : RT_TRAV_DONE;
+    t.cur = (sc.has_root && aabb_distance(o, t.inv(), ld3(sc.root_min), ld3(sc.root_max)) <= 1e12f) ? sc.root_entry : RT_TRAV_DONE;
 }
 
 __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
@@ -374,12 +393,30 @@ __device__ __forceinline__ void load_cached_item(int item, int n_cached, float4&
     q3 = make_float4(a3.x, a3.y, a3.z, a3.w);
 }
 
-// AABBIntersectDistance again, without branches, for the traversal loop.  Same values as aabb_distance:
-// a = mn - o and b = mx - o are the differences the slab test forms anyway, and "o inside the box"
-// (mn <= o <= mx on every axis) is "every a <= 0 and every b >= 0" because an f32 difference has the
-// sign of the exact one (denormals are kept); box bounds and ray origins are never NaN.  tmin cannot be
-// negative (it starts at 0 and only grows), so the reference's `tmin < 0` exit is dead.
-__device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {
+// AABBIntersectDistance (main.cu:73-117) once more, for the traversal loop: no branches, and the x/y and
+// z components of one child box as two-float vectors (v_pk_add_f32 / v_pk_mul_f32).  Same values as
+// aabb_distance: a = mn - o and b = mx - o are the differences the slab test forms anyway, and "o inside
+// the box" (mn <= o <= mx on every axis) is "every a <= 0 and every b >= 0" because an f32 difference
+// has the sign of the exact one (denormals are kept); box bounds and ray origins are never NaN.  tmin
+// cannot be negative (it starts at 0 and only grows), so the reference's `tmin < 0` exit is dead.
+__device__ __forceinline__ float aabb_distance_pk(v2f oxy, v2f ozz, v2f ixy, v2f izz, v2f mn_xy, v2f mx_xy, v2f mnmx_z) {
+    const v2f a = mn_xy - oxy, b = mx_xy - oxy, z = mnmx_z - ozz;  // z = (a.z, b.z)
+    const bool inside = fmaxf(fmaxf(a.x, a.y), z.x) <= 0.0f && fminf(fminf(b.x, b.y), z.y) >= 0.0f;
+    const v2f t1 = a * ixy, t2 = b * ixy, tz = z * izz;
+    float tmin = fmaxf(0.0f, fminf(t1.x, t2.x));
+    float tmax = fminf(1e13f, fmaxf(t1.x, t2.x));
+    tmin = fmaxf(tmin, fminf(t1.y, t2.y));
+    tmax = fminf(tmax, fmaxf(t1.y, t2.y));
+    tmin = fmaxf(tmin, fminf(tz.x, tz.y));
+    tmax = fminf(tmax, fmaxf(tz.x, tz.y));
+    const float r = (tmax < tmin) ? 1e13f : tmin;
+    return inside ? 0.0f : r;
+}
+
+#ifndef RT_INNER_PK
+#define RT_INNER_PK 1
+#endif
+__device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {  // scalar form of aabb_distance_pk
     const f3 a = mn - o, b = mx - o;
     const bool inside = fmaxf(fmaxf(a.x, a.y), a.z) <= 0.0f && fminf(fminf(b.x, b.y), b.z) >= 0.0f;
     const f3 t1 = a * inv, t2 = b * inv;
@@ -397,8 +434,14 @@ __device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {
 template <bool STATS>
 __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, float4 q0, float4 q1, float4 q2, float4 q3) {
     if (STATS) cn.inner++;
-    float dA = aabb_distance_nb(t.o, t.inv, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y));
-    float dB = aabb_distance_nb(t.o, t.inv, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w));
+#if RT_INNER_PK
+    const v2f oxy = t.oxy, ozz = {t.oz, t.oz}, ixy = t.ixy, izz = {t.iz, t.iz};
+    float dA = aabb_distance_pk(oxy, ozz, ixy, izz, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q2.x, q2.y});
+    float dB = aabb_distance_pk(oxy, ozz, ixy, izz, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.z, q2.w});
+#else
+    float dA = aabb_distance_nb(t.o(), t.inv(), mk(q0.x, q0.y, q2.x), mk(q0.z, q0.w, q2.y));
+    float dB = aabb_distance_nb(t.o(), t.inv(), mk(q1.x, q1.y, q2.z), mk(q1.z, q1.w, q2.w));
+#endif
     dA = dA * dA;
     dB = dB * dB;
     const int eA = __float_as_int(q3.x), eB = __float_as_int(q3.y);
@@ -415,10 +458,12 @@ template <bool STATS>
 __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, float4 q0, float4 q1, float4 q2) {
     const int flags = __float_as_int(q2.y);
     if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
-    f3 pos;
-    if (ray_triangle(t.o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), pos)) {
-        const float nd = len2(pos - t.o);
-        if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = t.cur - sc.n_inner; }
+    float ht;
+    const f3 o = t.o();
+    if (ray_triangle_t(o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht)) {
+        const f3 pos = o + t.d * ht;
+        const float nd = len2(pos - o);
+        if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = t.cur - sc.n_inner; }
     }
     if (flags & 1) trav_pop(t, stk);
     else t.cur++;
@@ -479,10 +524,12 @@ __device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Count
         const float4* h = sc.items + 4 * ((size_t)sc.n_inner + i);
         const float4 h0 = h[0], h1 = h[1], h2 = h[2];
         if (STATS) cn.tri++;
-        f3 pos;
-        if (ray_triangle(t.o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), pos)) {
-            const float nd = len2(pos - t.o);
-            if (nd < t.minD2) { t.minD2 = nd; t.hitPos = pos; t.hitTri = i; }
+        float ht;
+        const f3 o = t.o();
+        if (ray_triangle_t(o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), ht)) {
+            const f3 pos = o + t.d * ht;
+            const float nd = len2(pos - o);
+            if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = i; }
         }
     }
     t.cur = RT_TRAV_DONE;
@@ -494,8 +541,8 @@ __device__ __forceinline__ int trav_spheres(const Scene& sc, Trav& t, f3& sPos) 
     for (int i = 0; i < sc.n_spheres; i++) {
         const float4 s0 = sc.spheres[2 * i];
         f3 hp, hn;
-        if (intersect_sphere(t.o, t.d, mk(s0.x, s0.y, s0.z), s0.w, hp, hn)) {
-            const float d2 = len2(hp - t.o);
+        if (intersect_sphere(t.o(), t.d, mk(s0.x, s0.y, s0.z), s0.w, hp, hn)) {
+            const float d2 = len2(hp - t.o());
             if (d2 >= t.minD2) continue;
             t.minD2 = d2;
             sPos = hp;
@@ -533,7 +580,7 @@ __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool 
 #endif
     hitTri = t.hitTri;
     minD2 = t.minD2;
-    hitPos = t.hitPos;
+    hitPos = t.hitTri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------ shading (material.h)
