@@ -437,8 +437,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     }
 }
 
-// Adds the chunk's samples of every pixel, in sample order, to the accumulator (thread = pixel of a tile).
-__global__ void rt_sum_samples_kernel(const float* __restrict__ samples, float* __restrict__ accum, Params P, int chunk_S) {
+// Adds the chunk's samples of every pixel, in sample order, to the pixel's running sum of this call (thread = pixel of a
+// tile).  The running sum starts at 0 in the first chunk, is parked in `carry` between chunks and is added to the
+// accumulator after the last one: accum += ((0 + e_0) + e_1) + ... however the call was cut into chunks.
+__global__ void rt_sum_samples_kernel(const float* __restrict__ samples, float* __restrict__ accum, float* __restrict__ carry, Params P,
+                                      int chunk_S, int first, int last) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)P.n_tiles * 64) return;
     const unsigned int tile = (unsigned int)(i >> 6), pi = (unsigned int)(i & 63);
@@ -447,15 +450,22 @@ __global__ void rt_sum_samples_kernel(const float* __restrict__ samples, float* 
     if (x >= P.width || r >= P.rows) return;
     const float* s = samples + ((size_t)tile * chunk_S * 64 + pi) * 3;
     f3 c = mk(0.f, 0.f, 0.f);
+    if (!first) c = ld3(carry + 3 * i);
     for (int k = 0; k < chunk_S; k++, s += 64 * 3) {
         c.x += s[0];
         c.y += s[1];
         c.z += s[2];
     }
-    float* a = accum + ((size_t)r * P.width + x) * 3;
-    a[0] += c.x;
-    a[1] += c.y;
-    a[2] += c.z;
+    if (last) {
+        float* a = accum + ((size_t)r * P.width + x) * 3;
+        a[0] += c.x;
+        a[1] += c.y;
+        a[2] += c.z;
+    } else {
+        carry[3 * i] = c.x;
+        carry[3 * i + 1] = c.y;
+        carry[3 * i + 2] = c.z;
+    }
 }
 
 // =============================================================================== wavefront pipeline
@@ -1446,12 +1456,13 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
     long long S = std::min<long long>(P.sample_count, std::max<long long>(1, (long long)(budget / (slots * 12))));
     S = std::min<long long>(S, (long long)(0x7fffffffu / slots));  // 32-bit path counter
     if (S < 1) return set_err(c, RT_ERR_LIMIT, "image too large for the path-parallel kernel");
-    while (c->samples_floats < slots * (size_t)S * 3) {
+    // S samples per pixel + one more slot per pixel for the running sum carried between chunks
+    while (c->samples_floats < slots * (size_t)(S + 1) * 3) {
         if (c->d_samples) (void)hipFree(c->d_samples);
         c->d_samples = nullptr;
         c->samples_floats = 0;
-        if (hipMalloc((void**)&c->d_samples, slots * (size_t)S * 12) == hipSuccess) {
-            c->samples_floats = slots * (size_t)S * 3;
+        if (hipMalloc((void**)&c->d_samples, slots * (size_t)(S + 1) * 12) == hipSuccess) {
+            c->samples_floats = slots * (size_t)(S + 1) * 3;
             break;
         }
         (void)hipGetLastError();
@@ -1484,7 +1495,8 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
             ev_used += 2;
         }
-        hipLaunchKernelGGL(rt_sum_samples_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c->stream, c->d_samples, accum, P, s);
+        hipLaunchKernelGGL(rt_sum_samples_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, c->stream, c->d_samples, accum,
+                           c->d_samples + slots * (size_t)S * 3, P, s, (int)(k0 == 0), (int)(k0 + s >= P.sample_count));
     }
     HIP_TRY(c, hipGetLastError());
     if (out && profile && ev_used) {  // RT_F_PROFILE: summed duration of the path kernel's launches alone

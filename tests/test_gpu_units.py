@@ -251,6 +251,28 @@ def test_motion_blur_and_ragged_image_sizes(ob, rt, gpu, scenes, mode):
         assert np.array_equal(gpu.readback(), o), (w, h)
 
 
+def test_sample_chunks_of_the_path_kernel(ob, rt, gpu, scenes, monkeypatch):
+    """The path-parallel kernel keeps one radiance per (pixel, sample) of a chunk; with a 1 MB buffer a 40-spp call
+    runs in three chunks and a ragged image pads its edge tiles -- the per-pixel sums must not change by one bit."""
+    sc = scenes("scene.txt")
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=40, width=93, height=61, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
+    gpu.reset(); st = gpu.render(p); one = gpu.readback()
+    monkeypatch.setenv("RT_SAMPLE_BUF_MB", "1")            # 12 x 8 tiles x 64 x 12 B = 73.7 KB per sample -> 14 spp per chunk
+    gpu.reset(); st_c = gpu.render(p); chunked = gpu.readback()
+    monkeypatch.delenv("RT_SAMPLE_BUF_MB")
+    assert np.array_equal(one, chunked)
+    assert (st.paths, st.rays, st.tri_tests) == (st_c.paths, st_c.rays, st_c.tri_tests) and st.paths == 93 * 61 * 40
+    o, ost = ob.render(sc, p, n_threads=8)
+    assert np.array_equal(one, o) and st.rays == ost.rays
+    # progressive use: two calls of 20 samples accumulate like the lock-step kernel does
+    q = rt.RenderParams.from_buffer_copy(p); q.sample_count = 20
+    gpu.reset(); gpu.render(q); q.sample_begin = 20; gpu.render(q); two = gpu.readback()
+    ql = rt.RenderParams.from_buffer_copy(q); ql.flags |= rt.F_LOCKSTEP; ql.sample_begin = 0
+    gpu.reset(); gpu.render(ql); ql.sample_begin = 20; gpu.render(ql)
+    assert np.array_equal(two, gpu.readback())
+
+
 def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
     mt = rt.Material(); mt.type = 3; mt.color = 0xFFFFFF; mt.image_offset[:] = [-1, -1, -1]
     sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mt])
