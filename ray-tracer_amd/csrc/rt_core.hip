@@ -214,6 +214,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_TRI_MIN
 #define RT_TRI_MIN 16  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
+#ifndef RT_BIG_LEAF
+#define RT_BIG_LEAF 48
+#endif
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
 #endif
@@ -395,7 +398,17 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         const bool at_inner = trav_at_inner(sc, t);
         const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
         const unsigned long long mLeaf = __ballot(at_leaf);
-        if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
+        unsigned long long mBig = sc.tri_soa ? __ballot(t.cur >= RT_ENTRY_BIG) : 0ull;
+        if (mBig) {  // big leaves at once, with the whole wave, whoever else waits
+            do {
+                const int lcur = __builtin_amdgcn_readlane(t.cur, __ffsll((long long)mBig) - 1);
+                const unsigned long long owners = __ballot(t.cur == lcur);  // lanes at the same leaf share its loads
+                RT_PROF_COUNT(cn, 0, 1);
+                if (t.cur == lcur) RT_PROF_LANE(cn, 1);
+                trav_big_leaf<STATS>(sc, t, stk, cn, lcur & ~RT_ENTRY_BIG, owners);
+                mBig &= ~owners;
+            } while (mBig);
+        } else if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
@@ -961,7 +974,7 @@ struct rt_context {
     // scene (device)
     bool has_scene = false;
     Scene sc{};
-    void* d_items = nullptr; void* d_cold = nullptr;
+    void* d_items = nullptr; void* d_cold = nullptr; void* d_soa = nullptr;
     void* d_mats = nullptr; void* d_lights = nullptr; void* d_spheres = nullptr; void* d_tex = nullptr;
     int bvh_depth = 0;
 
@@ -1003,7 +1016,7 @@ int set_err(rt_context* c, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(rt_context* c) {
-    void** ptrs[] = {&c->d_items, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
+    void** ptrs[] = {&c->d_items, &c->d_soa, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -1209,11 +1222,17 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (max_depth > RT_STACK_ENTRIES)
         return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
+    int big_leaf = RT_BIG_LEAF;  // leaves with at least this many triangles are tested by the whole wave
+    if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(1, atoi(e));  // experiments only
+    bool any_big = false;
     auto entry_of = [&](int node) -> int {
         const rt_bvh_node& n = s->nodes[node];
         if (n.child_a != -1) return inner_index[node];
         if (n.tri_len == 0) return RT_TRAV_EMPTY;
-        return n_inner + n.tri_offs / RT_TRI_FLOATS;
+        const int e = n_inner + n.tri_offs / RT_TRI_FLOATS;
+        if (n.tri_len / RT_TRI_FLOATS < big_leaf) return e;
+        any_big = true;
+        return e | RT_ENTRY_BIG;
     };
     std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
     std::vector<float> cold((size_t)std::max(ntri, 1) * 16, 0.f);
@@ -1301,8 +1320,20 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         d[4] = i2f(static_cast<int>(q[4]));
     }
 
+    const int root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    std::vector<float> soa;
+    if (any_big) {  // blocks of 64 triangles: 64 x q0, 64 x q1, 64 x q2
+        soa.assign(((size_t)ntri + 63) / 64 * 192 * 4, 0.f);
+        for (int i = 0; i < ntri; i++) {
+            const float* h = &items[((size_t)n_inner + i) * 16];
+            for (int k = 0; k < 3; k++)
+                memcpy(&soa[(((size_t)i >> 6) * 192 + (size_t)k * 64 + (i & 63)) * 4], h + 4 * k, 16);
+        }
+    }
+
     free_scene(c);
     int rc;
+    if (any_big && (rc = upload_buf(c, &c->d_soa, soa.data(), soa.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_items, items.data(), items.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_cold, cold.data(), cold.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_mats, mats.data(), mats.size() * 4)) != RT_OK) return rc;
@@ -1312,6 +1343,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
 
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
+    sc.tri_soa = (const float4*)c->d_soa;
     sc.n_inner = n_inner;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
@@ -1324,7 +1356,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.n_lights = s->n_light_tris;
     sc.n_spheres = s->n_spheres;
     sc.has_root = nn > 0;
-    sc.root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    sc.root_entry = root_entry;
     for (int k = 0; k < 3; k++) {
         sc.root_min[k] = nn > 0 ? s->nodes[0].bbox_min[k] : 0.f;
         sc.root_max[k] = nn > 0 ? s->nodes[0].bbox_max[k] : 0.f;

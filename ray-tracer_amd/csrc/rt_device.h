@@ -43,6 +43,7 @@ namespace rtd {
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
     const float4* items;
+    const float4* tri_soa;   // triangles once more, in blocks of 64: [q0 x 64][q1 x 64][q2 x 64]; null without big leaves
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
@@ -327,7 +328,11 @@ struct Attractor {
 extern __shared__ float4 rt_lds[];  // dynamic LDS: [4 * n_cached node pieces][per-lane stacks]
 
 #define RT_TRAV_DONE (-1)   // query finished
-#define RT_TRAV_EMPTY 0x7ffffff0  // a leaf without triangles (visited, nothing to test); sorts after every item index
+#define RT_TRAV_EMPTY 0x3ffffff0  // a leaf without triangles (visited, nothing to test); sorts after every item index
+// Entry of a leaf with at least RT_BIG_LEAF triangles: item index | RT_ENTRY_BIG.  The path-parallel kernel tests
+// such a leaf with the whole wave (64 triangles per step, coalesced loads from tri_soa); everywhere else the bit
+// is masked off and the leaf is walked one triangle at a time.
+#define RT_ENTRY_BIG 0x40000000
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -455,7 +460,8 @@ __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, flo
 
 // One triangle test of the current leaf (main.cu:249-264) on the fetched item.
 template <bool STATS>
-__device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, float4 q0, float4 q1, float4 q2) {
+__device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, int item, float4 q0, float4 q1,
+                                               float4 q2) {
     const int flags = __float_as_int(q2.y);
     if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
     float ht;
@@ -463,7 +469,7 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
     if (ray_triangle_t(o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht)) {
         const f3 pos = o + t.d * ht;
         const float nd = len2(pos - o);
-        if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = t.cur - sc.n_inner; }
+        if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = item - sc.n_inner; }
     }
     if (flags & 1) trav_pop(t, stk);
     else t.cur++;
@@ -480,14 +486,15 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
         return;
     }
     float4 q0, q1, q2, q3;
+    const int item = t.cur & ~RT_ENTRY_BIG;
     if (t.cur < n_cached) {
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
-        const float4* w = sc.items + 4 * (size_t)t.cur;
+        const float4* w = sc.items + 4 * (size_t)item;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
     if (t.cur < sc.n_inner) visit_inner<STATS>(t, stk, cn, q0, q1, q2, q3);
-    else visit_triangle<STATS>(sc, t, stk, cn, q0, q1, q2);
+    else visit_triangle<STATS>(sc, t, stk, cn, item, q0, q1, q2);
 }
 
 // The two kinds of step on their own, for schedulers that run them in separate wave-uniform phases
@@ -513,8 +520,55 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
         trav_pop(t, stk);
         return;
     }
-    const float4* w = sc.items + 4 * (size_t)t.cur;
-    visit_triangle<STATS>(sc, t, stk, cn, w[0], w[1], w[2]);
+    const int item = t.cur & ~RT_ENTRY_BIG;
+    const float4* w = sc.items + 4 * (size_t)item;
+    visit_triangle<STATS>(sc, t, stk, cn, item, w[0], w[1], w[2]);
+}
+
+// A whole BIG leaf for every lane of `owners` (all of them stand at its first triangle, entry `first_item`):
+// per step the 64 lanes load 64 consecutive triangles of the leaf (coalesced, from tri_soa) and test them
+// against one owner's ray after the other, the ray travelling through v_readlane.  Same result as the walk of
+// main.cu:249-264: a later triangle replaces the hit only if strictly closer, so the winner is the closest
+// hit and, among equals, the first in array order -- candidates are taken in lane (= array) order with the
+// same strict comparison.
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <bool STATS>
+__device__ __forceinline__ void trav_big_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int first_item,
+                                              unsigned long long owners) {
+    const int lane = threadIdx.x & 63;
+    for (int base = first_item - sc.n_inner;; base += 64) {  // triangle index of lane 0
+        const int tri = base + lane;
+        const bool in_array = tri < sc.n_tris;
+        const int tc = in_array ? tri : sc.n_tris - 1;
+        const float4* w = sc.tri_soa + (size_t)(tc >> 6) * 192 + (tc & 63);
+        const float4 q0 = w[0], q1 = w[64], q2 = w[128];
+        const unsigned long long mLast = __ballot(in_array && (__float_as_int(q2.y) & 1));
+        const int n_valid = mLast ? __ffsll((long long)mLast) : 64;  // triangles of the leaf in this step
+        const f3 v0 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+        for (unsigned long long m = owners; m; m &= m - 1) {
+            const int ow = __ffsll((long long)m) - 1;
+            const f3 o = mk(lane_f(t.oxy.x, ow), lane_f(t.oxy.y, ow), lane_f(t.oz, ow));
+            const f3 d = mk(lane_f(t.d.x, ow), lane_f(t.d.y, ow), lane_f(t.d.z, ow));
+            float best = lane_f(t.minD2, ow);
+            float ht = 0.0f, nd = 0.0f;
+            bool hit = lane < n_valid && ray_triangle_t(o, d, v0, e1, e2, ht);
+            if (hit) nd = len2((o + d * ht) - o);
+            int winner = -1;
+            for (unsigned long long mc = __ballot(hit && nd < best); mc; mc &= mc - 1) {
+                const int l = __ffsll((long long)mc) - 1;
+                const float ndl = lane_f(nd, l);
+                if (ndl < best) { best = ndl; winner = l; }
+            }
+            if (winner >= 0) {
+                const float htw = lane_f(ht, winner);
+                if (lane == ow) { t.minD2 = best; t.set_hit(htw, mk(0.f, 0.f, 0.f)); t.hitTri = base + winner; }
+            }
+            if (STATS && lane == ow) { cn.tri += n_valid; cn.leaf += (base == first_item - sc.n_inner); }
+        }
+        if (mLast) break;
+    }
+    if ((owners >> lane) & 1) trav_pop(t, stk);
 }
 
 // ENABLE_BVH false, main.cu:285-301

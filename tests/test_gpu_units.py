@@ -273,6 +273,25 @@ def test_sample_chunks_of_the_path_kernel(ob, rt, gpu, scenes, monkeypatch):
     assert np.array_equal(two, gpu.readback())
 
 
+@pytest.mark.parametrize("depth", [2, 5, 8])
+def test_big_leaves_whole_wave_test(ob, rt, gpu, depth):
+    """Shallow trees over scene.txt / a small dragon field: leaves of 48 triangles and more are tested by the whole
+    wave in the path kernel (64 triangles per step, several owners per leaf).  Sums and counters as the oracle's
+    and the one-triangle-per-step kernels'; leaves of 47 and fewer keep the per-lane walk in the same run."""
+    sc = rt.Scene.load("scene.txt", bvh_max_depth=depth)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=3, width=72, height=56, max_bounces=5, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
+    gpu.reset(); st = gpu.render(p); img = gpu.readback()
+    o, ost = ob.render(sc, p, n_threads=8)
+    assert np.array_equal(img, o)
+    assert (st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == \
+           (ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
+    for m in ("lockstep", "wavefront"):
+        q = rt.RenderParams.from_buffer_copy(p); q.flags = rt.F_DEFAULT | rt.F_STATS | rt.MODE_FLAGS[m]
+        gpu.reset(); st2 = gpu.render(q)
+        assert np.array_equal(gpu.readback(), img) and st2.tri_tests == st.tri_tests, m
+
+
 def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
     mt = rt.Material(); mt.type = 3; mt.color = 0xFFFFFF; mt.image_offset[:] = [-1, -1, -1]
     sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mt])
