@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_LANE_NEW (-2)
 #define RT_LANE_IDLE (-3)
 
-template <bool STATS>
+template <bool STATS, bool BIG>  // BIG: the scene has big leaves (Scene::tri_soa), tested by the whole wave
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         const bool at_inner = trav_at_inner(sc, t);
         const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
         const unsigned long long mLeaf = __ballot(at_leaf);
-        unsigned long long mBig = sc.tri_soa ? __ballot(t.cur >= RT_ENTRY_BIG) : 0ull;
+        unsigned long long mBig = BIG ? __ballot(t.cur >= RT_ENTRY_BIG) : 0ull;
         if (mBig) {  // big leaves at once, with the whole wave, whoever else waits
             do {
                 const int lcur = __builtin_amdgcn_readlane(t.cur, __ffsll((long long)mBig) - 1);
@@ -1451,8 +1451,10 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     c->mega_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
@@ -1502,7 +1504,9 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         S = (S + 1) / 2;
     }
     typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
-    const paths_fn kfn = want_stats ? rt_render_paths_kernel<true> : rt_render_paths_kernel<false>;
+    const bool big = c->sc.tri_soa != nullptr;
+    const paths_fn kfn = big ? (want_stats ? rt_render_paths_kernel<true, true> : rt_render_paths_kernel<false, true>)
+                             : (want_stats ? rt_render_paths_kernel<true, false> : rt_render_paths_kernel<false, false>);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     size_t ev_used = 0;
