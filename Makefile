@@ -8,7 +8,9 @@ LIBDIR  := $(PKG)/lib
 CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
 # -ffp-contract=off: the closest-hit arithmetic must be evaluated exactly as written
 # (no FMA) so primitive ids match the oracle bit for bit.
-HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
+# -fno-slp-vectorize: packed v_pk_*_f32 pairs cost register shuffles and issue no faster here (measured
+# 39.2 -> 36.2 ms per frame on the bench scene with everything scalar, profiles/r01_ab_megakernel.txt).
+HIPFLAGS := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
             -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Iinclude
 
 all: $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so $(LIBDIR)/rtcli oracle

@@ -419,7 +419,7 @@ __device__ __forceinline__ float aabb_distance_pk(v2f oxy, v2f ozz, v2f ixy, v2f
 }
 
 #ifndef RT_INNER_PK
-#define RT_INNER_PK 1
+#define RT_INNER_PK 0  // 1 = the packed two-float form below: fewer instructions, slower (v_pk_*_f32 issues at half rate)
 #endif
 __device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {  // scalar form of aabb_distance_pk
     const f3 a = mn - o, b = mx - o;
