@@ -5,7 +5,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 PKG     := ray-tracer_amd
 LIBDIR  := $(PKG)/lib
-CXXFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
+CXXFLAGS := -std=c++17 -O2 -fPIC -pthread -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Iinclude
 # -ffp-contract=off: the closest-hit arithmetic must be evaluated exactly as written
 # (no FMA) so primitive ids match the oracle bit for bit.
 # -fno-slp-vectorize: packed v_pk_*_f32 pairs cost register shuffles and issue no faster here (measured

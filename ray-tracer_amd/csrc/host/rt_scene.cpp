@@ -9,14 +9,18 @@
 #include "rt_scene.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -356,8 +360,8 @@ bool parse_obj(const std::string& path, ParsedObj& o, std::string& err) {
 }
 
 // Model::loadMesh, model.h:62-163: v' = (R*v)*scale + T ; n' = R*n ; records in face order.
-void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index,
-                  std::vector<float>& out) {
+// Records of one instance into w[0 .. 25 * triangles).
+void emit_records_to(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index, float* w) {
     const Mat3 R = rotation_matrix(rot);
     std::vector<float> verts(o.v.size()), norms(o.vn.size());
     for (size_t i = 0; i < o.v.size(); i += 3) {
@@ -373,9 +377,6 @@ void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, i
         norms[i] = r.x; norms[i + 1] = r.y; norms[i + 2] = r.z;
     }
     const float matf = (float)((double)static_cast<float>(material_index) + 0.001);  // model.h:162
-    const size_t base = out.size();
-    out.resize(base + o.idx.size() / 9 * RT_TRI_FLOATS);
-    float* w = out.data() + base;
     for (size_t i = 0; i < o.idx.size(); i += 9, w += RT_TRI_FLOATS) {
         for (int k = 0; k < 3; k++) {
             const int vi = (o.idx[i + k] - 1) * 3;
@@ -404,130 +405,222 @@ void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, i
     }
 }
 
+void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index,
+                  std::vector<float>& out) {
+    const size_t base = out.size();
+    out.resize(base + o.idx.size() / 9 * RT_TRI_FLOATS);
+    emit_records_to(o, T, scale, rot, material_index, out.data() + base);
+}
+
+// Stage timer: RT_SCENE_TIMING=1 prints the wall time of the scene-assembly stages to stderr.
+struct StageTimer {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() {
+        static const bool on = getenv("RT_SCENE_TIMING") != nullptr;
+        if (on) fprintf(stderr, "[rt_scene] %-28s %8.1f ms\n", name,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // ------------------------------------------------------------------ BVH
+
+// Host worker threads for the data-parallel parts of scene assembly (RT_HOST_THREADS overrides; at most 16).
+int host_threads() {
+    static const int n = [] {
+        int t = (int)std::thread::hardware_concurrency();
+        if (const char* e = getenv("RT_HOST_THREADS")) t = atoi(e);
+        return std::max(1, std::min(t, 16));
+    }();
+    return n;
+}
+
+// fn(i) for i in [0, n), dynamically scheduled over the host threads.
+template <class F>
+void parallel_for(size_t n, size_t grain, F fn) {
+    const int nt = (int)std::min<size_t>((size_t)host_threads(), (n + grain - 1) / std::max<size_t>(grain, 1));
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t b = next.fetch_add(grain);
+            if (b >= n) return;
+            const size_t e = std::min(n, b + grain);
+            for (size_t i = b; i < e; i++) fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
 
 struct TmpNode {
     float mn[3], mx[3];
-    std::vector<uint32_t> tris;  // triangle indices (records), input order preserved
+    uint32_t begin = 0, end = 0;  // its triangles: ids[begin, end), input order preserved
     int a = -1, b = -1;
     int depth = 0;
-    int index = -1;
 };
 
-inline void grow_box(float* mn, float* mx, const float* tri) {
-    for (int v = 0; v < 3; v++) {
-        mn[0] = fminf(mn[0], tri[v * 3 + 0]);
-        mn[1] = fminf(mn[1], tri[v * 3 + 1]);
-        mn[2] = fminf(mn[2], tri[v * 3 + 2]);
-        mx[0] = fmaxf(mx[0], tri[v * 3 + 0]);
-        mx[1] = fmaxf(mx[1], tri[v * 3 + 1]);
-        mx[2] = fmaxf(mx[2], tri[v * 3 + 2]);
-    }
-}
-
-// splitNode, BVHcreator.cpp:86-170.  Returns false if the node stays a leaf.
-bool split_node(std::vector<TmpNode>& nodes, int ni, const float* tris) {
-    {
-        TmpNode& n = nodes[ni];
-        if (n.tris.size() <= 2) return false;  // :97-99
-    }
-    const int ia = (int)nodes.size();
-    nodes.emplace_back();
-    nodes.emplace_back();
-    TmpNode& n = nodes[ni];
-    TmpNode& A = nodes[ia];
-    TmpNode& B = nodes[ia + 1];
-    n.a = ia;
-    n.b = ia + 1;
-    A.depth = B.depth = n.depth + 1;
-    const float xw = n.mx[0] - n.mn[0], yw = n.mx[1] - n.mn[1], zw = n.mx[2] - n.mn[2];
-    int axis;
-    if (xw >= yw && xw >= zw) axis = 0;
-    else if (yw >= xw && yw >= zw) axis = 1;
-    else axis = 2;
-    float mean = 0.0f;  // float accumulation in triangle order, :113-123
-    for (uint32_t t : n.tris) {
-        const float* tri = tris + (size_t)t * RT_TRI_FLOATS;
-        mean += (tri[axis] + tri[3 + axis] + tri[6 + axis]);
-    }
-    mean /= static_cast<float>(n.tris.size() * 3);
-    for (uint32_t t : n.tris) {
-        const float* tri = tris + (size_t)t * RT_TRI_FLOATS;
-        const float c = (tri[axis] + tri[3 + axis] + tri[6 + axis]) / 3.0f;
-        if (c < mean) A.tris.push_back(t);
-        else B.tris.push_back(t);
-    }
-    for (TmpNode* c : {&A, &B}) {
-        c->mn[0] = c->mn[1] = c->mn[2] = 1e12f;
-        c->mx[0] = c->mx[1] = c->mx[2] = -1e12f;
-        for (uint32_t t : c->tris) grow_box(c->mn, c->mx, tris + (size_t)t * RT_TRI_FLOATS);
-    }
-    n.tris.clear();
-    n.tris.shrink_to_fit();
-    return true;
-}
-
-// createBVH, BVHcreator.cpp:240-256 (+ createInitialNode :187-205, splitRecursive
-// :173-184, BFSIndex :41-61, populateBVHNodes :209-237).
+// createBVH, BVHcreator.cpp:240-256 (createInitialNode :187-205, splitRecursive :173-184, splitNode :86-170,
+// BFSIndex :41-61, populateBVHNodes :209-237) -- same tree, same numbering, same triangle order, built level by
+// level instead of recursively:
+//  * per triangle, the three vertex sums a+b+c per axis (what both the mean and the centroid test of splitNode add
+//    up, :113-135) and its box are formed once (12 + 24 bytes instead of gathers from 100-byte records);
+//  * a node owns a range of ONE id array; splitting is a stable partition of that range, so both children keep the
+//    input order the reference's push_back loops produce;
+//  * the mean stays a serial float accumulation in triangle order (its rounding is part of the result); nodes of a
+//    level are independent and run on the host threads; big nodes partition and bound their ranges in parallel
+//    chunks (min/max are exact, so chunking cannot change a box);
+//  * children are created A then B in parent order, which IS the reference's BFS numbering.
 int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::vector<rt_bvh_node>& out,
               int* out_depth) {
     if (n_floats % RT_TRI_FLOATS != 0) return fail("triangle array length is not a multiple of 25");
     const size_t ntri = n_floats / RT_TRI_FLOATS;
     if (ntri > 0x7fffffffu / RT_TRI_FLOATS) return fail("too many triangles for int32 float offsets");
-    std::vector<TmpNode> nodes;
-    nodes.reserve(1024);
-    nodes.emplace_back();
+    size_t chunk = (size_t)1 << 18;  // triangles per parallel chunk of a big node (RT_BVH_CHUNK: tests force small chunks)
+    if (const char* e = getenv("RT_BVH_CHUNK")) chunk = (size_t)std::max(1, atoi(e));
+    std::vector<float> csum(ntri * 3), tbox(ntri * 6);
+    std::vector<uint32_t> ids(ntri), tmp(ntri);
+    std::vector<TmpNode> nodes(1);
     {
-        TmpNode& r = nodes[0];
-        r.depth = 0;
-        r.mn[0] = r.mn[1] = r.mn[2] = 1e12f;
-        r.mx[0] = r.mx[1] = r.mx[2] = -1e12f;
-        r.tris.resize(ntri);
-        for (size_t i = 0; i < ntri; i++) {
-            grow_box(r.mn, r.mx, tris + i * RT_TRI_FLOATS);
-            r.tris[i] = (uint32_t)i;
+        StageTimer tm("bvh: per-triangle sums, boxes");
+        parallel_for(ntri, 1 << 16, [&](size_t i) {
+            const float* t = tris + i * RT_TRI_FLOATS;
+            float* bx = &tbox[i * 6];
+            for (int c = 0; c < 3; c++) {
+                csum[i * 3 + c] = t[c] + t[3 + c] + t[6 + c];
+                bx[c] = fminf(fminf(fminf(1e12f, t[c]), t[3 + c]), t[6 + c]);
+                bx[3 + c] = fmaxf(fmaxf(fmaxf(-1e12f, t[c]), t[3 + c]), t[6 + c]);
+            }
+            ids[i] = (uint32_t)i;
+        });
+    }
+    // box of ids[b, e): fold of the per-triangle boxes (starts at +-1e12 like createInitialNode / splitNode)
+    auto range_box = [&](uint32_t b, uint32_t e, float* mn, float* mx) {
+        const size_t n = e - b, nchunks = (n + chunk - 1) / chunk;
+        std::vector<float> part(std::max<size_t>(nchunks, 1) * 6);
+        auto fold = [&](size_t k) {
+            float* p = &part[k * 6];
+            p[0] = p[1] = p[2] = 1e12f;
+            p[3] = p[4] = p[5] = -1e12f;
+            const size_t lo = b + k * chunk, hi = std::min<size_t>(e, lo + chunk);
+            for (size_t i = lo; i < hi; i++) {
+                const float* bx = &tbox[(size_t)ids[i] * 6];
+                for (int c = 0; c < 3; c++) { p[c] = fminf(p[c], bx[c]); p[3 + c] = fmaxf(p[3 + c], bx[3 + c]); }
+            }
+        };
+        if (nchunks > 1) parallel_for(nchunks, 1, fold);
+        else fold(0);
+        for (int c = 0; c < 3; c++) { mn[c] = 1e12f; mx[c] = -1e12f; }
+        for (size_t k = 0; k < std::max<size_t>(nchunks, 1); k++)
+            for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], part[k * 6 + c]); mx[c] = fmaxf(mx[c], part[k * 6 + 3 + c]); }
+    };
+    nodes[0].begin = 0;
+    nodes[0].end = (uint32_t)ntri;
+    range_box(0, (uint32_t)ntri, nodes[0].mn, nodes[0].mx);
+
+    StageTimer* tm_split = new StageTimer("bvh: splits");
+    std::vector<int> level{0}, splitting;
+    int deepest_leaf = 0;
+    while (!level.empty()) {
+        splitting.clear();
+        for (int ni : level) {  // splitRecursive :173-184, splitNode :97-99
+            const TmpNode& n = nodes[ni];
+            const uint32_t cnt = n.end - n.begin;
+            if (n.depth >= max_depth || (int)cnt <= min_tris || cnt <= 2) { deepest_leaf = std::max(deepest_leaf, n.depth); continue; }
+            splitting.push_back(ni);
         }
+        const size_t first_child = nodes.size();
+        nodes.resize(first_child + 2 * splitting.size());
+        for (size_t k = 0; k < splitting.size(); k++) {
+            TmpNode& n = nodes[splitting[k]];
+            n.a = (int)(first_child + 2 * k);
+            n.b = n.a + 1;
+            nodes[n.a].depth = nodes[n.b].depth = n.depth + 1;
+        }
+        auto split_one = [&](size_t k) {
+            TmpNode& n = nodes[splitting[k]];
+            TmpNode& A = nodes[n.a];
+            TmpNode& B = nodes[n.b];
+            const float xw = n.mx[0] - n.mn[0], yw = n.mx[1] - n.mn[1], zw = n.mx[2] - n.mn[2];
+            int axis;
+            if (xw >= yw && xw >= zw) axis = 0;
+            else if (yw >= xw && yw >= zw) axis = 1;
+            else axis = 2;
+            const uint32_t b = n.begin, e = n.end, cnt = e - b;
+            float mean = 0.0f;  // float accumulation in triangle order, :113-123
+            for (uint32_t i = b; i < e; i++) mean += csum[(size_t)ids[i] * 3 + axis];
+            mean /= static_cast<float>((size_t)cnt * 3);
+            // stable partition of ids[b, e): centroid < mean goes to A (:125-135)
+            const size_t nchunks = ((size_t)cnt + chunk - 1) / chunk;
+            std::vector<uint32_t> na(nchunks + 1, 0);
+            auto count = [&](size_t c) {
+                const size_t lo = b + c * chunk, hi = std::min<size_t>(e, lo + chunk);
+                uint32_t m = 0;
+                for (size_t i = lo; i < hi; i++) m += (csum[(size_t)ids[i] * 3 + axis] / 3.0f < mean) ? 1u : 0u;
+                na[c + 1] = m;
+            };
+            if (nchunks > 1) parallel_for(nchunks, 1, count);
+            else count(0);
+            for (size_t c = 0; c < nchunks; c++) na[c + 1] += na[c];
+            const uint32_t total_a = na[nchunks];
+            auto scatter = [&](size_t c) {
+                const size_t lo = b + c * chunk, hi = std::min<size_t>(e, lo + chunk);
+                uint32_t pa = b + na[c], pb = b + total_a + (uint32_t)(lo - b) - na[c];
+                for (size_t i = lo; i < hi; i++) {
+                    const uint32_t t = ids[i];
+                    if (csum[(size_t)t * 3 + axis] / 3.0f < mean) tmp[pa++] = t;
+                    else tmp[pb++] = t;
+                }
+            };
+            if (nchunks > 1) parallel_for(nchunks, 1, scatter);
+            else scatter(0);
+            memcpy(&ids[b], &tmp[b], (size_t)cnt * sizeof(uint32_t));
+            A.begin = b; A.end = b + total_a;
+            B.begin = b + total_a; B.end = e;
+            range_box(A.begin, A.end, A.mn, A.mx);
+            range_box(B.begin, B.end, B.mn, B.mx);
+        };
+        // few big nodes: one after the other, each using the threads inside; many small nodes: one node per task
+        if (splitting.size() < (size_t)host_threads() * 2) for (size_t k = 0; k < splitting.size(); k++) split_one(k);
+        else parallel_for(splitting.size(), 1, split_one);
+        level.clear();
+        for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
     }
-    // depth-first A-then-B like splitRecursive (order of creation does not
-    // matter for the result; numbering is assigned by the BFS below).
-    std::vector<int> todo{0};
-    while (!todo.empty()) {
-        const int ni = todo.back();
-        todo.pop_back();
-        if (nodes[ni].depth >= max_depth || (int)nodes[ni].tris.size() <= min_tris) continue;
-        if (!split_node(nodes, ni, tris)) continue;
-        todo.push_back(nodes[ni].b);
-        todo.push_back(nodes[ni].a);
-    }
-    // BFS numbering, A before B.
-    std::vector<int> order;
-    order.reserve(nodes.size());
-    order.push_back(0);
-    for (size_t head = 0; head < order.size(); head++) {
-        TmpNode& n = nodes[order[head]];
-        n.index = (int)head;
-        if (n.a >= 0) order.push_back(n.a);
-        if (n.b >= 0) order.push_back(n.b);
-    }
-    out.resize(order.size());
-    std::vector<float> newtris(n_floats);
-    int offs = 0, depth = 0;
-    for (size_t k = 0; k < order.size(); k++) {
-        const TmpNode& n = nodes[order[k]];
+    delete tm_split;
+    StageTimer tm_out("bvh: numbering + reorder");
+    // creation order is BFS order, A before B (BFSIndex :41-61); triangles leaf by leaf in that order
+    out.resize(nodes.size());
+    std::vector<size_t> src_begin(nodes.size());
+    int offs = 0;
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const TmpNode& n = nodes[k];
         rt_bvh_node& o = out[k];
         for (int c = 0; c < 3; c++) { o.bbox_min[c] = n.mn[c]; o.bbox_max[c] = n.mx[c]; }
-        o.child_a = n.a >= 0 ? nodes[n.a].index : -1;
-        o.child_b = n.b >= 0 ? nodes[n.b].index : -1;
+        o.child_a = n.a;
+        o.child_b = n.b;
         o.tri_offs = offs;
-        o.tri_len = (int)n.tris.size() * RT_TRI_FLOATS;
-        for (uint32_t t : n.tris) {
-            memcpy(&newtris[offs], tris + (size_t)t * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
-            offs += RT_TRI_FLOATS;
-        }
-        if (n.a < 0) depth = std::max(depth, n.depth);
+        o.tri_len = n.a < 0 ? (int)(n.end - n.begin) * RT_TRI_FLOATS : 0;
+        offs += o.tri_len;
     }
-    if (n_floats) memcpy(tris, newtris.data(), n_floats * sizeof(float));
-    if (out_depth) *out_depth = depth;
+    std::unique_ptr<float[]> newtris(new float[std::max<size_t>(n_floats, 1)]);  // (not zero-filled: every float is written below)
+    parallel_for(nodes.size(), 64, [&](size_t k) {
+        const TmpNode& n = nodes[k];
+        if (n.a >= 0) return;
+        float* dst = &newtris[(size_t)out[k].tri_offs];
+        for (uint32_t i = n.begin; i < n.end; i++, dst += RT_TRI_FLOATS)
+            memcpy(dst, tris + (size_t)ids[i] * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
+    });
+    if (n_floats) {
+        const size_t cp = (size_t)1 << 22, nch = (n_floats + cp - 1) / cp;
+        parallel_for(nch, 1, [&](size_t c) { memcpy(tris + c * cp, &newtris[c * cp], std::min(cp, n_floats - c * cp) * sizeof(float)); });
+    }
+    if (out_depth) *out_depth = deepest_leaf;
     return RT_OK;
 }
 
@@ -751,21 +844,30 @@ rt_material blank_material() {
 // light list + marker removal, sceneParser.cpp:455-470
 void extract_lights(float* tris, size_t n_floats, std::vector<int32_t>& lights) {
     lights.clear();
-    for (size_t i = 0; i < n_floats; i += RT_TRI_FLOATS) {
-        if (tris[i + 24] > 1000.0f) {
-            tris[i + 24] -= 1000.0f;
-            lights.push_back(static_cast<int32_t>(i));
+    const size_t ntri = n_floats / RT_TRI_FLOATS, chunk = (size_t)1 << 18, nch = (ntri + chunk - 1) / chunk;
+    std::vector<std::vector<int32_t>> part(nch);
+    parallel_for(nch, 1, [&](size_t c) {
+        for (size_t t = c * chunk; t < std::min(ntri, (c + 1) * chunk); t++) {
+            const size_t i = t * RT_TRI_FLOATS;
+            if (tris[i + 24] > 1000.0f) {
+                tris[i + 24] -= 1000.0f;
+                part[c].push_back(static_cast<int32_t>(i));
+            }
         }
-    }
+    });
+    for (auto& p : part) lights.insert(lights.end(), p.begin(), p.end());  // ascending offsets, like the serial scan
 }
 
 int finish_geometry(rt_host_scene* sc, std::vector<float>& records, int max_depth, int min_tris) {
     // prefix (sphere block) already in sc->tris
     const size_t prefix = sc->tris.size();
-    sc->tris.resize(prefix + records.size());
-    if (!records.empty()) memcpy(sc->tris.data() + prefix, records.data(), records.size() * sizeof(float));
-    records.clear();
-    records.shrink_to_fit();
+    if (prefix == 0) {
+        sc->tris.swap(records);  // no sphere block in front: take the records as they are
+    } else {
+        sc->tris.resize(prefix + records.size());
+        if (!records.empty()) memcpy(sc->tris.data() + prefix, records.data(), records.size() * sizeof(float));
+    }
+    std::vector<float>().swap(records);
     int rc = build_bvh(sc->tris.data() + prefix, sc->tris.size() - prefix, max_depth, min_tris, sc->nodes, &sc->bvh_depth);
     if (rc != RT_OK) return rc;
     extract_lights(sc->tris.data() + prefix, sc->tris.size() - prefix, sc->lights);
@@ -1131,19 +1233,29 @@ int rt_scene_synth_field(const char* obj_path, int instances, uint32_t seed, con
     const float cell = 1.6f;
     std::mt19937 rng(seed);
     auto uni = [&]() { return (float)(rng() >> 8) * (1.0f / 16777216.0f); };
-    std::vector<float> records;
-    records.reserve((size_t)instances * (po.idx.size() / 9) * RT_TRI_FLOATS + 2 * RT_TRI_FLOATS);
+    // the random draws in instance order (one stream), then the instances in parallel
+    struct Inst { V3 pos, rot; float scale; int mat; };
+    std::vector<Inst> inst((size_t)instances);
     const float scale = 1.0f / extent;
     for (int k = 0; k < instances; k++) {
         const int gx = k % side, gz = k / side;
-        V3 pos;
-        pos.x = (gx - 0.5f * (side - 1)) * cell + (uni() - 0.5f) * 0.4f;
-        pos.y = 0.0f;
-        pos.z = -3.0f - gz * cell + (uni() - 0.5f) * 0.4f;
-        V3 rot{0.f, uni() * 6.2831853f, 0.f};
-        const int mat = 1 + (k % 3);
-        emit_records(po, pos, scale * (0.8f + 0.6f * uni()), rot, mat, records);
+        Inst& in = inst[(size_t)k];
+        in.pos.x = (gx - 0.5f * (side - 1)) * cell + (uni() - 0.5f) * 0.4f;
+        in.pos.y = 0.0f;
+        in.pos.z = -3.0f - gz * cell + (uni() - 0.5f) * 0.4f;
+        in.rot = V3{0.f, uni() * 6.2831853f, 0.f};
+        in.mat = 1 + (k % 3);
+        in.scale = scale * (0.8f + 0.6f * uni());
     }
+    const size_t per_inst = po.idx.size() / 9 * RT_TRI_FLOATS;
+    std::vector<float> records;
+    records.reserve((size_t)instances * per_inst + 2 * RT_TRI_FLOATS);
+    records.resize((size_t)instances * per_inst);
+    StageTimer* tm_emit = new StageTimer("synth: instance records");
+    parallel_for((size_t)instances, 1, [&](size_t k) {
+        const Inst& in = inst[k];
+        emit_records_to(po, in.pos, in.scale, in.rot, in.mat, records.data() + k * per_inst);
+    });
     {   // ground quad (two triangles), material 0
         const float hx = 0.5f * side * cell + 4.0f, z0 = 2.0f, z1 = -3.0f - side * cell - 4.0f;
         const float q[4][3] = {{-hx, 0.f, z0}, {hx, 0.f, z0}, {hx, 0.f, z1}, {-hx, 0.f, z1}};
@@ -1160,8 +1272,14 @@ int rt_scene_synth_field(const char* obj_path, int instances, uint32_t seed, con
             records.insert(records.end(), r, r + RT_TRI_FLOATS);
         }
     }
-    int rc = finish_geometry(sc, records, bvh_max_depth, bvh_min_tris);
+    delete tm_emit;
+    int rc;
+    {
+        StageTimer tm("synth: finish_geometry");
+        rc = finish_geometry(sc, records, bvh_max_depth, bvh_min_tris);
+    }
     if (rc != RT_OK) { delete sc; return rc; }
+    StageTimer tm_env("synth: materials + env");
     // materials: 0 ground Lambert, 1 Lambert, 2 glossy (type 0), 3 metal (type 4)
     rt_material m = blank_material();
     m.type = 3; m.color = color_to_int(V3{0.5f, 0.6f, 0.55f}); sc->mats.push_back(m);

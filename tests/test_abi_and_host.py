@@ -265,6 +265,27 @@ def test_bvh_matches_python_restatement(rt, n, seed):
     assert np.array_equal(got_tris, exp_tris)
 
 
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+def test_bvh_parallel_chunks_change_nothing(rt, monkeypatch, chunk):
+    """Big nodes count / scatter / bound their triangle range in parallel chunks (2^18 triangles by default, far
+    above these sizes): forcing tiny chunks must give the same nodes and the same triangle order."""
+    tris = random_soup(600, 4)
+    exp_nodes, exp_tris = py_bvh(tris)
+    monkeypatch.setenv("RT_BVH_CHUNK", str(chunk))
+    got_nodes, got_tris = build(rt, tris)
+    assert len(got_nodes) == len(exp_nodes)
+    for g, e in zip(got_nodes, exp_nodes):
+        assert g[2:] == e[2:]
+        assert np.array_equal(np.float32(g[0]), np.float32(e[0])) and np.array_equal(np.float32(g[1]), np.float32(e[1]))
+    assert np.array_equal(got_tris, exp_tris)
+    big = random_soup(20000, 11)
+    monkeypatch.delenv("RT_BVH_CHUNK")
+    ref_nodes, ref_tris = build(rt, big)
+    monkeypatch.setenv("RT_BVH_CHUNK", str(chunk * 13))
+    got_nodes, got_tris = build(rt, big)
+    assert got_nodes == ref_nodes and np.array_equal(got_tris, ref_tris)
+
+
 def test_bvh_cornell_matches_python_restatement(rt, scenes):
     # rebuild from the (already reordered) cornell records: same records -> same tree shape
     s = scenes("scene_cornellbox.txt")
