@@ -113,8 +113,11 @@ enum {
     RT_F_DEFOCUS = 1 << 2,      /* ENABLE_DEFOCUS_BLUR  config.h:10 */
     RT_F_BVH = 1 << 3,          /* ENABLE_BVH           config.h:16 (off = brute force, main.cu:285-301) */
     RT_F_SPHERES = 1 << 4,      /* ENABLE_SPHERES       config.h:13 */
-    RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9  (reserved, rejected) */
-    RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14 (reserved, rejected) */
+    RT_F_VOLUME = 1 << 5,       /* ENABLE_VOLUME_SCATTERING config.h:9: homogeneous scattering inside type-6 volumes
+                                   (checkScatteredVolume, main.cu:127-141, 338, 350).  Fused kernel only. */
+    RT_F_RAYMARCH = 1 << 6,     /* ENABLE_RAY_MARCHING  config.h:14: rays bent by a point mass at the origin (marchRay,
+                                   main.cu:143-153, 225-227, 364-372); max_bounces is the step count
+                                   (RAY_MARCHING_MAX_STEPS, config.h:15).  Fused kernel only. */
     RT_F_STATS = 1 << 8,        /* count rays / node visits / triangle tests */
     RT_F_MEGAKERNEL = 1 << 9,   /* force the fused persistent kernel (path-parallel: lanes take (pixel, sample) paths
                                    one by one, per-path radiance summed per pixel in sample order afterwards) */
@@ -257,13 +260,17 @@ int rt_shade_hits(rt_context* ctx, const float* in, size_t n, uint32_t seed, flo
  * normal  = sqrtf(-2 logf(u_a)) * cosf(RT_TWO_PI_F * u_b) from two consecutive dims.
  * Dimensions: 0 animation time (main.cu:179), 1-2 anti-alias jitter (:200-201),
  * 4-5 lens theta, r (:120-121); bounce j owns dims 8+8j .. 15+8j, consumed in
- * the reference's call order inside Material::reflect / Sphere::hitSphere. */
+ * the reference's call order inside Material::reflect / Sphere::hitSphere;
+ * the volume check of bounce j (checkScatteredVolume, main.cu:127-141, RT_F_VOLUME)
+ * owns dims RT_RNG_DIM_VOLUME0 + 4j .. +2: free-flight draw, Vec3::randSphere r1, r2. */
 #define RT_RNG_TAG 0x52544131u
 #define RT_RNG_KEY1 0x9E3779B9u
 #define RT_RNG_DIM_CAMERA 0
 #define RT_RNG_DIM_LENS 4
 #define RT_RNG_DIM_BOUNCE0 8
 #define RT_RNG_DIMS_PER_BOUNCE 8
+#define RT_RNG_DIM_VOLUME0 0x80000000u
+#define RT_RNG_DIMS_PER_VOLUME 4
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,7 @@ inline Vec3 operator+(const Vec3& a, const Vec3& b) { return Vec3(a.x + b.x, a.y
 inline Vec3 operator-(const Vec3& a, const Vec3& b) { return Vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
 inline Vec3 operator*(const Vec3& a, const Vec3& b) { return Vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
 inline Vec3 operator*(const Vec3& a, float s) { return Vec3(a.x * s, a.y * s, a.z * s); }
+inline Vec3 operator/(const Vec3& a, float s) { return Vec3(a.x / s, a.y / s, a.z / s); }  // vec3.h:195-197
 inline Vec3 lerp(const Vec3& a, const Vec3& b, float t) {  // vec3.h:125-131
     return Vec3(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z));
 }
@@ -128,9 +129,12 @@ struct Ray {
     Vec3 position, direction, diffuseMultiplier, emission;
     float refractiveIndex, volumeDensity;
     Vec3 volumeColor;
+    Vec3 marchVelocity;
     Ray(const Vec3& o, const Vec3& d)
         : position(o), direction(d), diffuseMultiplier(1.f, 1.f, 1.f), emission(0.f, 0.f, 0.f),
-          refractiveIndex(1.0f), volumeDensity(0.0f), volumeColor(1.f, 1.f, 1.f) {}
+          refractiveIndex(1.0f), volumeDensity(0.0f), volumeColor(1.f, 1.f, 1.f) {
+        marchVelocity = direction * 0.1f;  // ray.h:30
+    }
     void marchForward(float dist) {
         Vec3 s = direction * dist;
         position.x += s.x;
@@ -386,9 +390,9 @@ struct Hit {
 };
 
 void closest_hit(const Scene& sc, const Vec3& org, const Vec3& dir, bool use_bvh, Hit& h, Counters& c,
-                 int* max_stack = nullptr) {
+                 int* max_stack = nullptr, float minDistSqr0 = 1e12f) {
     h.tri = -1;
-    h.minDistSqr = 1e12f;
+    h.minDistSqr = minDistSqr0;  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     c.rays++;
     if (use_bvh) {
         // The reference's stack has BVH_DEPTH (16) slots although a depth-16 tree
@@ -741,11 +745,49 @@ Ray camera_ray(const rt_render_params& p, int x, int y, Rng& rng) {
     return Ray(rayOrigin, dir);
 }
 
+// checkScatteredVolume, main.cu:127-141.  Its three draws (free-flight distance, Vec3::randSphere's two) come
+// from dimensions RT_RNG_DIM_VOLUME0 + 4 j of the path's stream (rt.h): a bounce's own eight are all taken.
+bool check_scattered_volume(Ray& ray, const Vec3& hitPos, Rng& rng, uint32_t bounce) {
+    if (ray.volumeDensity <= 0.0f) return false;
+    rng.seek(RT_RNG_DIM_VOLUME0 + RT_RNG_DIMS_PER_VOLUME * bounce);
+    float r = rng.uniform();
+    float travel_dist = -pm::log(r) / ray.volumeDensity;
+    float dist_to_target = (hitPos - ray.position).length();
+    if (travel_dist > dist_to_target) return false;  // no scattering
+    Vec3 step = ray.direction * travel_dist;
+    ray.position.x += step.x;
+    ray.position.y += step.y;
+    ray.position.z += step.z;
+    ray.direction = rand_sphere_vec(rng);
+    ray.diffuseMultiplier = ray.diffuseMultiplier * ray.volumeColor;
+    return true;
+}
+
+// marchRay, main.cu:143-153
+void march_ray(Ray& ray) {
+    const float dt = 1.0f;
+    const float G = 10000000.0f;
+    float r2 = ray.position.lengthSqr() + 1e-5f;
+    Vec3 acceleration = ray.position / (r2 * sqrtf(r2)) * -1.0f;
+    Vec3 dv = acceleration * dt * G;
+    ray.marchVelocity.x += dv.x;
+    ray.marchVelocity.y += dv.y;
+    ray.marchVelocity.z += dv.z;
+    Vec3 lastPos = ray.position;
+    Vec3 dp = ray.marchVelocity * dt;
+    ray.position.x += dp.x;
+    ray.position.y += dp.y;
+    ray.position.z += dp.z;
+    ray.direction = (ray.position - lastPos).normalize();
+}
+
 // One pixel's sum over samples [sample_begin, sample_begin+sample_count): main.cu:176-390
 Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Counters& c) {
     Vec3 color(0.f, 0.f, 0.f);
     const bool use_bvh = (p.flags & RT_F_BVH) != 0;
     const bool spheres_on = (p.flags & RT_F_SPHERES) != 0 && sc.numSpheres > 0;
+    const bool volume = (p.flags & RT_F_VOLUME) != 0;    // ENABLE_VOLUME_SCATTERING, config.h:9
+    const bool marching = (p.flags & RT_F_RAYMARCH) != 0;  // ENABLE_RAY_MARCHING, config.h:14 (max_bounces = RAY_MARCHING_MAX_STEPS)
     const Vec3 bg(p.background[0], p.background[1], p.background[2]);
     const uint32_t pixel = (uint32_t)(x + y * p.cam.width);
     for (int k = 0; k < p.sample_count; k++) {
@@ -754,8 +796,9 @@ Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Coun
         c.paths++;
         for (int j = 0; j < p.max_bounces; j++) {
             rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)j);
-            Hit h;
-            closest_hit(sc, ray.position, ray.direction, use_bvh, h, c);
+            Hit h;  // (h.pos = 0: `Vec3 hitPos;` of main.cu:221)
+            closest_hit(sc, ray.position, ray.direction, use_bvh, h, c, nullptr,
+                        marching ? ray.marchVelocity.lengthSqr() : 1e12f);
             if (spheres_on) {  // main.cu:305-346
                 bool closestHitIsSphere = false;
                 int hitSphereIndex = 0;
@@ -774,6 +817,9 @@ Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Coun
                     }
                 }
                 if (closestHitIsSphere) {
+                    // main.cu:338 hands checkScatteredVolume the TRIANGLE hit position (zero without one), as here
+                    if (volume && check_scattered_volume(ray, h.pos, rng, (uint32_t)j)) continue;
+                    rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)j);
                     // Reference indexes materials[hitSphereIndex + 4] (main.cu:341), which is
                     // the wrong array; the material id stored in the sphere record is used.
                     int mi = static_cast<int>(sc.spheres[hitSphereIndex + 4]);
@@ -784,6 +830,8 @@ Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Coun
                 }
             }
             if (h.tri >= 0) {
+                if (volume && check_scattered_volume(ray, h.pos, rng, (uint32_t)j)) continue;  // main.cu:350-352
+                rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)j);
                 c.hits++;
                 int hitIndex = static_cast<int>(sc.tris[h.tri + 24]);
                 rt_material m;
@@ -798,6 +846,15 @@ Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Coun
                 normalize_inplace(ray.direction);
             } else {
                 Vec3 e;
+                if (marching) {  // main.cu:364-372: no hit within this step, so march; the backdrop only far from the origin
+                    march_ray(ray);
+                    if (ray.position.lengthSqr() > 20.0f * 20.0f) {
+                        e = bg * ray.diffuseMultiplier * p.background_brightness;
+                        color.x += e.x; color.y += e.y; color.z += e.z;
+                        break;
+                    }
+                    continue;
+                }
                 if ((p.flags & RT_F_SKYBOX) && p.cam.env_width > 0) {
                     long long envI = env_index(ray.direction, p.cam.env_width, p.cam.env_height);
                     c.texels++;
@@ -843,7 +900,6 @@ int orc_rows(const rt_render_params* p) {
 int orc_render(const rt_scene_desc* scene, const rt_render_params* p, float* accum, rt_render_stats* stats,
                int n_threads) {
     if (!scene || !p || !accum) return RT_ERR_INVALID;
-    if (p->flags & (RT_F_VOLUME | RT_F_RAYMARCH)) return RT_ERR_INVALID;
     const Scene sc = view_of(scene);
     const int W = p->cam.width, H = p->cam.height;
     if (n_threads < 1) n_threads = 1;

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_LANE_NEW (-2)
 #define RT_LANE_IDLE (-3)
 
-template <bool STATS, bool BIG>  // BIG: the scene has big leaves (Scene::tri_soa), tested by the whole wave
+// BIG: the scene has big leaves (Scene::tri_soa), tested by the whole wave.  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
+// (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
+template <bool STATS, bool BIG, bool EXTRA>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
@@ -238,9 +240,13 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
+    const bool volume = EXTRA && (P.flags & RT_F_VOLUME) != 0;
+    const bool marching = EXTRA && (P.flags & RT_F_RAYMARCH) != 0;
     Counters cn;
     cn.clear();
     [[maybe_unused]] const unsigned long long plife0 = RT_PROF_CLOCK();
+    [[maybe_unused]] float volDensity = 0.0f;
+    [[maybe_unused]] f3 volColor = mk(1.f, 1.f, 1.f), marchVel = mk(0.f, 0.f, 0.f);
 
     // wave-uniform path source: paths [batch_next, batch_end) are not handed out yet
     unsigned int batch_next = 0, batch_end = 0;
@@ -280,30 +286,44 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 ray.thr = thr;
                 ray.emission = mk(0.f, 0.f, 0.f);
                 ray.ri = ri;
-                ray.volDensity = 0.0f;
-                ray.volColor = mk(1.f, 1.f, 1.f);
+                ray.volDensity = EXTRA ? volDensity : 0.0f;
+                ray.volColor = EXTRA ? volColor : mk(1.f, 1.f, 1.f);
                 f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
                 bool alive = true, handled = false;
+                // main.cu:338, 350 hand checkScatteredVolume the TRIANGLE hit position (zero without one), also for spheres
+                const f3 triPos = (volume && t.hitTri >= 0) ? t.hit_pos() : mk(0.f, 0.f, 0.f);
                 if (spheres_on) {
                     f3 sPos;
                     const int hitSphere = trav_spheres(sc, t, sPos);
                     if (hitSphere >= 0) {
-                        const float4 s0 = sc.spheres[2 * hitSphere];
-                        const f3 sNrm = normalize(sPos - mk(s0.x, s0.y, s0.z));
-                        const int mat = __float_as_int(sc.spheres[2 * hitSphere + 1].x);
-                        if (STATS) cn.hits++;
-                        shade_sphere<STATS>(sc, ray, sNrm, sPos, mat, rng, bb, cn);
-                        handled = true;  // `continue` at main.cu:343: no renormalise
+                        if (!(volume && check_scattered_volume(ray, triPos, rng, (uint32_t)bounce))) {
+                            const float4 s0 = sc.spheres[2 * hitSphere];
+                            const f3 sNrm = normalize(sPos - mk(s0.x, s0.y, s0.z));
+                            const int mat = __float_as_int(sc.spheres[2 * hitSphere + 1].x);
+                            if (STATS) cn.hits++;
+                            shade_sphere<STATS>(sc, ray, sNrm, sPos, mat, rng, bb, cn);
+                        }
+                        handled = true;  // `continue` at main.cu:339, 343: no renormalise
                     }
                 }
                 if (!handled) {
                     if (t.hitTri >= 0) {
-                        if (STATS) cn.hits++;
-                        if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn)) {  // main.cu:357-360
-                            e = ray.emission * ray.thr;
-                            alive = false;
+                        if (volume && check_scattered_volume(ray, triPos, rng, (uint32_t)bounce)) {
+                            // scattered inside the volume: `continue`, main.cu:350-352
                         } else {
-                            ray.d = normalize_keep(ray.d);  // main.cu:361
+                            if (STATS) cn.hits++;
+                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn)) {  // main.cu:357-360
+                                e = ray.emission * ray.thr;
+                                alive = false;
+                            } else {
+                                ray.d = normalize_keep(ray.d);  // main.cu:361
+                            }
+                        }
+                    } else if (marching) {  // main.cu:364-372: nothing within this step, so march; the backdrop only far away
+                        march_ray(ray.o, ray.d, marchVel);
+                        if (len2(ray.o) > 20.0f * 20.0f) {
+                            e = ld3(P.bg) * ray.thr * P.bg_brightness;
+                            alive = false;
                         }
                     } else {  // main.cu:374-387
                         if ((P.flags & RT_F_SKYBOX) && P.env_w > 0) {
@@ -315,6 +335,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                         }
                         alive = false;
                     }
+                }
+                if (EXTRA) {
+                    volDensity = ray.volDensity;
+                    volColor = ray.volColor;
                 }
                 bounce++;
                 if (bounce >= P.max_bounces) alive = false;  // path exhausted: contributes 0
@@ -373,6 +397,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     thr = mk(1.f, 1.f, 1.f);
                     ri = 1.0f;
                     bounce = 0;
+                    if (EXTRA) {  // Ray::Ray, ray.h:22-31
+                        volDensity = 0.0f;
+                        volColor = mk(1.f, 1.f, 1.f);
+                        marchVel = t.d * 0.1f;
+                    }
                     if (STATS) cn.paths++;
                     if (P.max_bounces > 0) {
                         go = true;
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             }
             if (go) {  // main.cu:221-236
                 if (STATS) cn.rays++;
-                trav_begin(sc, t, ro, t.d);
+                trav_begin(sc, t, ro, t.d, marching ? len2(marchVel) : 1e12f);
                 if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
             }
             RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
@@ -1067,8 +1096,8 @@ int make_params(rt_context* c, const rt_render_params* p, Params& P) {
         return set_err(c, RT_ERR_INVALID, "image too large");
     if (p->sample_count < 0 || p->sample_begin < 0 || p->max_bounces < 0)
         return set_err(c, RT_ERR_INVALID, "negative sample/bounce count");
-    if (p->flags & (RT_F_VOLUME | RT_F_RAYMARCH))
-        return set_err(c, RT_ERR_INVALID, "volume scattering / ray marching are not implemented (off in reference config.h:9,14)");
+    if ((p->flags & (RT_F_VOLUME | RT_F_RAYMARCH)) && (p->flags & (RT_F_LOCKSTEP | RT_F_WAVEFRONT)))
+        return set_err(c, RT_ERR_INVALID, "volume scattering / ray marching run on the default fused kernel only");
     if (p->band_stride > 1 && (p->band_rows <= 0 || p->band_index < 0 || p->band_index >= p->band_stride))
         return set_err(c, RT_ERR_INVALID, "bad band partition");
     memset(&P, 0, sizeof(P));
@@ -1447,14 +1476,23 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
     return RT_OK;
 }
 
+typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
+paths_fn paths_kernel_variant(bool stats, bool big, bool extra) {
+    static const paths_fn table[8] = {
+        rt_render_paths_kernel<false, false, false>, rt_render_paths_kernel<true, false, false>,
+        rt_render_paths_kernel<false, true, false>,  rt_render_paths_kernel<true, true, false>,
+        rt_render_paths_kernel<false, false, true>,  rt_render_paths_kernel<true, false, true>,
+        rt_render_paths_kernel<false, true, true>,   rt_render_paths_kernel<true, true, true>};
+    return table[(stats ? 1 : 0) | (big ? 2 : 0) | (extra ? 4 : 0)];
+}
+
 int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_paths_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    for (int v = 0; v < 8; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     c->mega_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
@@ -1503,10 +1541,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         if (S == 1) return set_err(c, RT_ERR_NOMEM, "no device memory for the per-path radiance buffer");
         S = (S + 1) / 2;
     }
-    typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
-    const bool big = c->sc.tri_soa != nullptr;
-    const paths_fn kfn = big ? (want_stats ? rt_render_paths_kernel<true, true> : rt_render_paths_kernel<false, true>)
-                             : (want_stats ? rt_render_paths_kernel<true, false> : rt_render_paths_kernel<false, false>);
+    const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.tri_soa != nullptr, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     size_t ev_used = 0;

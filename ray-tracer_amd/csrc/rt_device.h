@@ -355,7 +355,7 @@ struct Trav {
 };
 
 // main.cu:221-236: reset the query and test the root box once.
-__device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d) {
+__device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d, float minD2_0 = 1e12f) {
     t.oxy = (v2f){o.x, o.y};
     t.oz = o.z;
     t.d = d;
@@ -363,7 +363,7 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d)
     t.iz = 1.0f / d.z;
     t.sp = 0;
     t.hitTri = -1;
-    t.minD2 = 1e12f;
+    t.minD2 = minD2_0;  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
     // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
     // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
@@ -901,6 +901,33 @@ __device__ __forceinline__ void shade_sphere(const Scene& sc, PathState& ray, f3
     const uint4 A = rng.block(bb);
     ray.d = normalize(normal + rand_sphere_vec(u01(A.x), u01(A.y)));
     ray.o = ray.o + ray.d * 1e-5f;
+}
+
+// checkScatteredVolume, main.cu:127-141 (ENABLE_VOLUME_SCATTERING).  Draws: Philox block
+// (RT_RNG_DIM_VOLUME0 + 4 * bounce) >> 2 of the path's stream: x free flight, y z Vec3::randSphere.
+__device__ __forceinline__ bool check_scattered_volume(PathState& ray, f3 hitPos, const Rng& rng, uint32_t bounce) {
+    if (ray.volDensity <= 0.0f) return false;
+    const uint4 V = rng.block((RT_RNG_DIM_VOLUME0 + RT_RNG_DIMS_PER_VOLUME * bounce) >> 2);
+    const float travel_dist = -pm::log(u01(V.x)) / ray.volDensity;
+    const float dist_to_target = sqrtf(len2(hitPos - ray.o));
+    if (travel_dist > dist_to_target) return false;  // no scattering
+    ray.o = ray.o + ray.d * travel_dist;
+    ray.d = rand_sphere_vec(u01(V.y), u01(V.z));
+    ray.thr = ray.thr * ray.volColor;
+    return true;
+}
+
+// marchRay, main.cu:143-153 (ENABLE_RAY_MARCHING)
+__device__ __forceinline__ void march_ray(f3& pos, f3& dir, f3& vel) {
+    const float dt = 1.0f;
+    const float G = 10000000.0f;
+    const float r2 = len2(pos) + 1e-5f;
+    const float s = r2 * sqrtf(r2);
+    const f3 acc = mk(pos.x / s, pos.y / s, pos.z / s) * -1.0f;
+    vel = vel + acc * dt * G;
+    const f3 last = pos;
+    pos = pos + vel * dt;
+    dir = normalize(pos - last);
 }
 
 // env lookup, main.cu:376-382 -> float index of the texel

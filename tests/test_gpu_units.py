@@ -292,6 +292,60 @@ def test_big_leaves_whole_wave_test(ob, rt, gpu, depth):
         assert np.array_equal(gpu.readback(), img) and st2.tri_tests == st.tri_tests, m
 
 
+VOLUME_SCENE = ("SET_OUTPUT_WIDTH 64\nSET_OUTPUT_HEIGHT 48\nSET_FOCAL_LENGTH 0.5\nSET_APERTURE_RADIUS 0.0\n\n"
+                "DEF_IMAGE env\nPATH cape_hill_1k.hdr\n\nDEF_MODEL pl\nPATH plane.obj\n\nDEF_MODEL cu\nPATH cube.obj\n\n"
+                "DEF_MODEL mo\nPATH monkey.obj\n\n"
+                "DEF_MATERIAL floor\nTYPE 3\nCOLOR 0.7 0.7 0.7\n\nDEF_MATERIAL glow\nTYPE 1\nCOLOR 1 0.9 0.8\nP1 6\n\n"
+                "DEF_MATERIAL fog\nTYPE 6\nCOLOR 0.9 0.6 0.3\nP1 1.5\n\nDEF_MATERIAL red\nTYPE 0\nCOLOR 0.8 0.2 0.2\nP1 0.2\nP2 0.3\n\n"
+                "DEF_OBJ f\nMODEL pl\nMATERIAL floor\n\nDEF_OBJ l\nMODEL pl\nMATERIAL glow\n\nDEF_OBJ v\nMODEL cu\nMATERIAL fog\n\n"
+                "DEF_OBJ m\nMODEL mo\nMATERIAL red\n\nSET_BACKGROUND env\n\n"
+                "ADD_OBJECT\nOBJECT f\nPOSITION 0 -1 -4\nSCALE 5.0\n\nADD_OBJECT\nOBJECT l\nPOSITION 0 2.5 -4\nROTATION 3.14159 0 0\nSCALE 1.0\n\n"
+                "ADD_OBJECT\nOBJECT v\nPOSITION 0 0 -3.5\nROTATION 0.2 0.4 0.0\nSCALE 0.9\n\n"
+                "ADD_OBJECT\nOBJECT m\nPOSITION 0.2 -0.1 -3.6\nSCALE 0.4\n\n"
+                "ADD_SPHERE\nPOSITION -1.4 -0.4 -3.5\nRADIUS 0.5\nMATERIAL floor\n")
+
+
+def test_volume_scattering_matches_oracle(ob, rt, gpu, tmp_path):
+    """ENABLE_VOLUME_SCATTERING (config.h:9, off in the reference): a type-6 cube around a monkey head; free-flight
+    scattering inside it (checkScatteredVolume) with and without analytic spheres.  Fused kernel only."""
+    f = tmp_path / "v.txt"
+    f.write_text(VOLUME_SCENE)
+    sc = rt.Scene.load(str(f), enable_spheres=True)
+    gpu.upload(sc)
+    base = None
+    for flags in (rt.F_DEFAULT, rt.F_DEFAULT | rt.F_VOLUME, rt.F_DEFAULT | rt.F_VOLUME | rt.F_SPHERES):
+        p = rt.default_params(sc.camera, spp=6, max_bounces=8, flags=flags | rt.F_STATS)
+        gpu.reset(); st = gpu.render(p); img = gpu.readback()
+        o, ost = ob.render(sc, p, n_threads=8)
+        assert np.array_equal(img, o), flags
+        assert (st.rays, st.hits, st.tri_tests, st.texel_fetches) == (ost.rays, ost.hits, ost.tri_tests, ost.texel_fetches)
+        if base is None:
+            base = img
+        else:
+            assert not np.array_equal(img, base)   # the volume is there
+    for m in (rt.F_LOCKSTEP, rt.F_WAVEFRONT):
+        p = rt.default_params(sc.camera, spp=1, flags=rt.F_DEFAULT | rt.F_VOLUME | m)
+        with pytest.raises(RuntimeError, match="fused kernel only"):
+            gpu.render(p)
+
+
+def test_ray_marching_matches_oracle(ob, rt, gpu, tmp_path):
+    """ENABLE_RAY_MARCHING (config.h:14): hits count only within |marchVelocity| of the ray origin, misses march
+    under the point mass at the origin (marchRay) and see the flat backdrop beyond 20 units."""
+    txt = VOLUME_SCENE.replace("POSITION 0 -1 -4\nSCALE 5.0", "POSITION 0 -0.04 -0.5\nSCALE 5.0")
+    f = tmp_path / "m.txt"
+    f.write_text(txt)
+    sc = rt.Scene.load(str(f))
+    gpu.upload(sc)
+    for flags in (rt.F_DEFAULT | rt.F_RAYMARCH, rt.F_DEFAULT | rt.F_RAYMARCH | rt.F_VOLUME):
+        p = rt.default_params(sc.camera, spp=4, max_bounces=25, flags=flags | rt.F_STATS)
+        gpu.reset(); st = gpu.render(p); img = gpu.readback()
+        o, ost = ob.render(sc, p, n_threads=8)
+        assert np.array_equal(img, o)
+        assert (st.rays, st.hits, st.tri_tests) == (ost.rays, ost.hits, ost.tri_tests)
+        assert st.hits > 0 and st.rays > st.paths          # some rays hit the floor under the camera, the others march
+
+
 def test_empty_scene_and_zero_bounces(ob, rt, gpu, scenes):
     mt = rt.Material(); mt.type = 3; mt.color = 0xFFFFFF; mt.image_offset[:] = [-1, -1, -1]
     sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mt])
@@ -328,8 +382,8 @@ def test_error_codes_instead_of_exit(rt, scenes):
         assert L.rt_upload_scene(h, C.byref(sc.desc)) == 0
         bad = rt.RenderParams.from_buffer_copy(p); bad.cam.width = 0
         assert L.rt_render(h, C.byref(bad), None) == -1
-        bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_RAYMARCH
-        assert L.rt_render(h, C.byref(bad), None) == -1 and b"not implemented" in L.rt_last_error(h)
+        bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_RAYMARCH | rt.F_WAVEFRONT
+        assert L.rt_render(h, C.byref(bad), None) == -1 and b"fused kernel only" in L.rt_last_error(h)
         bad = rt.RenderParams.from_buffer_copy(p); bad.band_rows, bad.band_stride, bad.band_index = 4, 2, 2
         assert L.rt_render(h, C.byref(bad), None) == -1
         bad = rt.RenderParams.from_buffer_copy(p); bad.cam.env_width, bad.cam.env_height = 4096, 2048   # larger than the pool

@@ -393,6 +393,48 @@ def test_furnace_emissive_wall(ob, rt):
     assert np.array_equal(acc, np.full((16, 16, 3), 8.0, np.float32)) and st.rays == st.paths
 
 
+def test_ray_marching_from_the_origin_known_answer(ob, rt):
+    """marchRay (main.cu:143-153), empty scene, camera at the origin: the first step sees no pull (position 0), moves
+    0.1 along the ray; the second is thrown ~1e9 units back through the origin (G / r^2) and, beyond 20 units, adds the
+    flat backdrop: two closest-hit queries per path, BACKGROUND_COLOR * BACKGROUND_BRIGHTNESS per sample."""
+    sc = rt.Scene.from_records(np.zeros((0, 25), np.float32), [mk_mat(rt, 3)])
+    p = rt.default_params(sc.camera, spp=3, width=8, height=4, max_bounces=100, flags=rt.F_DEFAULT | rt.F_RAYMARCH | rt.F_STATS)
+    p.cam.pos[:] = [0, 0, 0]
+    acc, st = ob.render(sc, p, n_threads=2)
+    assert np.array_equal(acc, np.broadcast_to(f32([1, 1, 0.05]) * f32(0.5) * 3, (4, 8, 3)))
+    assert st.paths == 96 and st.rays == 2 * st.paths
+    p.max_bounces = 1                                  # one step is not enough to get 20 units away: nothing is added
+    acc, st = ob.render(sc, p, n_threads=2)
+    assert not acc.any() and st.rays == st.paths
+
+
+def test_volume_scattering_dense_medium_known_answer(ob, rt):
+    """checkScatteredVolume (main.cu:127-141): a wall of type 6 with density 1e6 in front of an emissive wall.  With
+    the flag off the ray passes (type 6 only moves on) and sees the light; with it on, the light 2 units behind the
+    wall lies ~1e6 free flights (-log r / 1e6) away: the path scatters just behind the wall, tinted by the volume
+    colour each time, and either runs out of bounces (adds 0) or slips back out through the wall it entered by and
+    sees the flat backdrop (0.5 * BACKGROUND_COLOR * 0.50196^k) -- never the light."""
+    def quad(z, mat):
+        a = np.zeros((2, 25), np.float32)
+        a[0, 0:9] = [-50, -50, z, 50, -50, z, 50, 50, z]
+        a[1, 0:9] = [-50, -50, z, 50, 50, z, -50, 50, z]
+        a[:, 9:18] = np.tile([0, 0, 1], 3); a[:, 24] = mat + 0.001
+        return a
+    recs = np.concatenate([quad(-2, 0), quad(-4, 1)])
+    sc = rt.Scene.from_records(recs, [mk_mat(rt, 6, 0x808080, p1=1e6), mk_mat(rt, 1, 0xFFFFFF, p1=2.0)])
+    p = rt.default_params(sc.camera, spp=2, width=8, height=8, max_bounces=6, flags=rt.F_DEFAULT | rt.F_STATS)
+    p.cam.pos[:] = [0, 0, 0]
+    acc, st = ob.render(sc, p, n_threads=2)
+    assert np.array_equal(acc, np.full((8, 8, 3), 4.0, np.float32)) and st.rays == 2 * st.paths and st.hits == st.rays
+    p.flags |= rt.F_VOLUME
+    acc, st = ob.render(sc, p, n_threads=2)
+    tint = f32(0x80 / 255.0)
+    allowed = {0.0} | {float(f32(1.0) * (tint ** k) * f32(0.5)) for k in range(1, 6)}      # red/green channel of one sample
+    per_sample_max = max(allowed)
+    assert acc.max() <= 2 * per_sample_max + 1e-6 and acc.max() < 1.0 and (acc == 0).any()
+    assert st.rays > 2 * st.paths and st.hits < st.rays      # scattered bounces never reach a material
+
+
 def test_bounce_limit_contributes_zero(ob, rt, scenes):
     sc = scenes("scene_cornellbox.txt")
     p = rt.default_params(sc.camera, spp=2, width=16, height=16, max_bounces=0)
