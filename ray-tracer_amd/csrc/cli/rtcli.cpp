@@ -4,7 +4,7 @@
 // everything is a command-line option.
 //
 //   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
-//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--stats]
+//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--stats]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +17,7 @@
 
 static int usage() {
     fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
-                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--stats]\n");
+                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--stats]\n");
     return 2;
 }
 
@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     std::string scene, asset_root, out = "output.png", env;
     int spp = -1, bounces = 6, W = 0, H = 0, device = 0;
     unsigned seed = 37811;
-    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, want_stats = false;
+    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, want_stats = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
         else if (a == "--no-bvh") bvh = false;        // ENABLE_BVH, config.h:16
         else if (a == "--wavefront") wavefront = true;
         else if (a == "--lockstep") lockstep = true;
+        else if (a == "--volume") volume = true;
+        else if (a == "--raymarch") raymarch = true;
         else if (a == "--stats") want_stats = true;
         else return usage();
     }
@@ -77,7 +79,8 @@ int main(int argc, char** argv) {
     if (W > 0 && H > 0) { p.cam.width = W; p.cam.height = H; }
     p.max_bounces = bounces;
     p.flags = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | (bvh ? RT_F_BVH : 0) | (spheres ? RT_F_SPHERES : 0) |
-              (wavefront ? RT_F_WAVEFRONT : 0) | (lockstep ? RT_F_LOCKSTEP : 0) | (want_stats ? RT_F_STATS : 0);
+              (wavefront ? RT_F_WAVEFRONT : 0) | (lockstep ? RT_F_LOCKSTEP : 0) | (volume ? RT_F_VOLUME : 0) |
+              (raymarch ? RT_F_RAYMARCH : 0) | (want_stats ? RT_F_STATS : 0);
     p.seed = seed;
     p.sample_begin = 0;
     p.sample_count = spp > 0 ? spp : cam.num_samples;
