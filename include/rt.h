@@ -191,6 +191,11 @@ int rt_render(rt_context* ctx, const rt_render_params* params, rt_render_stats* 
  * inside the kernel).  n_floats must equal rows*width*3 of the last render. */
 int rt_readback(rt_context* ctx, float* rgb, size_t n_floats, int mode);
 
+/* The image the reference writes as PNG: average, toneMap (main.cu:392-406) and the 8-bit conversion of
+ * Texture::saveImgData (texture.cpp:53-56: static_cast<unsigned char>(v * 255), no clamp) done on the device; a
+ * quarter of the bytes of rt_readback cross PCIe.  n_bytes must equal rows*width*3 of the last render. */
+int rt_readback_rgb8(rt_context* ctx, unsigned char* rgb8, size_t n_bytes);
+
 /* Zero the accumulators and the sample counter. */
 int rt_reset_accum(rt_context* ctx);
 

@@ -84,6 +84,8 @@ int rt_image_load(const char* path, float** out_rgb, int* w, int* h);
  * with the reference's unclamped `(unsigned char)(v*255)` cast, .pfm = raw
  * float, .hdr = Radiance RGBE (flat). */
 int rt_image_save(const char* path, const float* rgb, int w, int h);
+/* Texture::saveImgData(const char*, const unsigned char*, int, int) (texture.cpp:64-66): 8-bit RGB as .png / .ppm. */
+int rt_image_save_rgb8(const char* path, const unsigned char* rgb8, int w, int h);
 
 void rt_host_free(void* p);
 

@@ -94,13 +94,13 @@ OP_STRIDES = {OP_TRI_INTERSECT: (15, 4), OP_AABB_DIST: (12, 1), OP_SPHERE: (10, 
               OP_CAMERA_RAY: (3, 6), OP_PMATH: (3, 2)}
 TRI_FLOATS = 25
 
-RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback",
+RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback", "rt_readback_rgb8",
               "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
               "rt_trace_rays", "rt_debug_op", "rt_shade_hits"]
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
-                 "rt_host_free"]
+                 "rt_image_save_rgb8", "rt_host_free"]
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -142,6 +142,7 @@ def scene_lib() -> C.CDLL:
         L.rt_noise_texture.argtypes = [C.c_int, C.c_int, _fp]
         L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(_fp), _ip, _ip]
         L.rt_image_save.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int]
+        L.rt_image_save_rgb8.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.rt_host_free.argtypes = [C.c_void_p]
         L.rt_host_free.restype = None
         _scene_lib = L
@@ -160,6 +161,7 @@ def core_lib() -> C.CDLL:
         L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(RenderStats)]
         L.rt_readback.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_int]
+        L.rt_readback_rgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_reset_accum.argtypes = [C.c_void_p]
         L.rt_bind_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_set_sample_count.argtypes = [C.c_void_p, C.c_int64]
@@ -360,6 +362,12 @@ class Renderer:
     def readback(self, mode: int = READ_RAW_SUM) -> np.ndarray:
         out = np.empty((self._rows, self._width, 3), np.float32)
         self._ck(self._L.rt_readback(self._h, _ptr(out), out.size, mode))
+        return out
+
+    def readback_rgb8(self) -> np.ndarray:
+        """Average + tone map + 8-bit conversion on the device (what the reference writes as PNG)."""
+        out = np.empty((self._rows, self._width, 3), np.uint8)
+        self._ck(self._L.rt_readback_rgb8(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
 
     def reset(self):

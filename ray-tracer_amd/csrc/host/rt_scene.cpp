@@ -1074,6 +1074,23 @@ int rt_image_save(const char* path, const float* rgb, int w, int h) {
     return RT_OK;
 }
 
+int rt_image_save_rgb8(const char* path, const unsigned char* rgb8, int w, int h) {
+    if (!path || !rgb8 || w <= 0 || h <= 0) return fail("bad image arguments");
+    const std::string p(path);
+    const bool png = ends_with(p, ".png");
+    if (!png && !ends_with(p, ".ppm")) return fail("unsupported 8-bit output format (need .png/.ppm): " + p);
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("could not open for writing: " + p);
+    if (png) {
+        write_png(f, rgb8, w, h);
+    } else {
+        fprintf(f, "P6\n%d %d\n255\n", w, h);
+        fwrite(rgb8, 1, (size_t)w * h * 3, f);
+    }
+    fclose(f);
+    return RT_OK;
+}
+
 int rt_scene_from_records(const float* tris, size_t n_floats, const rt_material* mats, size_t n_mats,
                           const float* textures, size_t n_tex_floats, int env_w, int env_h,
                           int bvh_max_depth, int bvh_min_tris, rt_host_scene** out) {

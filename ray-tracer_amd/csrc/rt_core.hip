@@ -850,6 +850,18 @@ __global__ void rt_resolve_kernel(const float* __restrict__ accum, float* __rest
     out[i * 3] = c.x; out[i * 3 + 1] = c.y; out[i * 3 + 2] = c.z;
 }
 
+// average + toneMap (main.cu:392-406) + the 8-bit conversion of Texture::saveImgData (texture.cpp:53-56)
+__global__ void rt_resolve_rgb8_kernel(const float* __restrict__ accum, unsigned char* __restrict__ out, size_t n_pixels, float samples) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    f3 c = mk(accum[i * 3], accum[i * 3 + 1], accum[i * 3 + 2]);
+    c.x /= samples; c.y /= samples; c.z /= samples;
+    c = tone_map(c);
+    out[i * 3] = (unsigned char)(int)(c.x * 255);
+    out[i * 3 + 1] = (unsigned char)(int)(c.y * 255);
+    out[i * 3 + 2] = (unsigned char)(int)(c.z * 255);
+}
+
 __global__ void rt_shade_kernel(Scene sc, const float* __restrict__ in, size_t n, unsigned seed, float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1728,6 +1740,26 @@ int rt_resolve_device(rt_context* c, float* dev_out, size_t n_floats, int mode) 
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
+}
+
+int rt_readback_rgb8(rt_context* c, unsigned char* rgb8, size_t n_bytes) {
+    if (!c || !rgb8) return RT_ERR_INVALID;
+    const size_t n = (size_t)c->acc_rows * c->acc_width * 3;
+    if (n == 0 || !accum_ptr(c)) return set_err(c, RT_ERR_INVALID, "nothing rendered yet");
+    if (n_bytes != n) return set_err(c, RT_ERR_INVALID, "n_bytes does not match rows*width*3 of the last render");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned char* tmp = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&tmp, n));
+    const size_t npix = n / 3;
+    const float samples = static_cast<float>(c->samples_done > 0 ? c->samples_done : 1);
+    hipLaunchKernelGGL(rt_resolve_rgb8_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, accum_ptr(c), tmp, npix, samples);
+    int rc = RT_OK;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb8, tmp, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = set_err(c, RT_ERR_DEVICE, std::string("8-bit readback: ") + hipGetErrorString(e));
+    (void)hipFree(tmp);
+    return rc;
 }
 
 int rt_readback(rt_context* c, float* rgb, size_t n_floats, int mode) {

@@ -6,6 +6,7 @@ Tolerances are the ones fixed in BASELINE.json / SURVEY.md 8(c):
   * images, same counter RNG, matched spp: relative mean-luminance diff <= 0.1 %, relRMSE <= 2 %
     (device libm differs from glibc by ulps in sin/cos/acos/atan2/asin/log, so a few paths diverge)
 """
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -126,6 +127,28 @@ def test_tonemapped_readback(ob, rt, gpu, scenes):
     assert np.array_equal(avg, ob.resolve(raw, 8, rt.READ_AVERAGE))
     ref = ob.resolve(raw, 8, rt.READ_TONEMAPPED)
     assert np.allclose(tm, ref, rtol=2e-6, atol=1e-7)
+
+
+def test_rgb8_readback_is_the_references_png_conversion(rt, gpu, scenes, tmp_path):
+    """rt_readback_rgb8 = toneMap + static_cast<unsigned char>(v * 255) (texture.cpp:53-56) on the device: the bytes the
+    host conversion of the float readback gives, and the PNG / PPM written from them decode to the same bytes."""
+    sc = scenes("scene.txt")
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=8, width=160, height=90)
+    gpu.reset(); gpu.render(p)
+    f = gpu.readback(rt.READ_TONEMAPPED)
+    b = gpu.readback_rgb8()
+    assert b.dtype == np.uint8 and b.shape == f.shape
+    assert np.array_equal(b, (f * np.float32(255)).astype(np.int32).astype(np.uint8))
+    L = rt.scene_lib()
+    path = str(tmp_path / "o.ppm").encode()
+    assert L.rt_image_save_rgb8(path, b.ctypes.data_as(C.c_void_p), 160, 90) == 0
+    raw = open(path, "rb").read()
+    assert raw.startswith(b"P6\n160 90\n255\n") and raw[len(b"P6\n160 90\n255\n"):] == b.tobytes()
+    png = str(tmp_path / "o.png").encode()
+    assert L.rt_image_save_rgb8(png, b.ctypes.data_as(C.c_void_p), 160, 90) == 0
+    assert L.rt_image_save(str(tmp_path / "f.png").encode(), f.ctypes.data_as(C.POINTER(C.c_float)), 160, 90) == 0
+    assert open(png, "rb").read() == open(str(tmp_path / "f.png"), "rb").read()     # same file as the float path writes
 
 
 def test_progressive_batches_equal_one_shot(rt, gpu, scenes):
