@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=0, help="use the synthetic instanced field instead of --scene")
+    ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
+                    help="sah = the NON-PARITY fast mode (binned-SAH tree, depth <= 24, leaves <= 2), reported separately")
     args = ap.parse_args()
 
     # torch first: its bundled HIP runtime has the same SONAME as /opt/rocm's, so librt_amd.so binds to
@@ -81,6 +83,9 @@ def main():
     else:
         scene = rt.Scene.load(args.scene)
         workload = f"{args.scene} ({scene.n_tris} triangles, {scene.desc.n_nodes} BVH nodes)"
+    if args.bvh == "sah":
+        scene.rebuild_bvh("sah")
+        workload += f" [non-parity SAH tree, {scene.desc.n_nodes} nodes]"
     W, H, spp = args.width, args.height, args.spp
 
     r = rt.Renderer(local_rank)
@@ -170,7 +175,7 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.synth_instances == 0 and args.scene == "scene.txt" and (W, H, spp) == (1920, 1080, 64):
+        if os.path.exists(pmc_path) and args.synth_instances == 0 and args.scene == "scene.txt" and args.bvh == "reference" and (W, H, spp) == (1920, 1080, 64):
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:

@@ -67,6 +67,19 @@ int rt_scene_bvh_depth(const rt_host_scene* s);
 int rt_bvh_build(float* tris, size_t n_floats, int max_depth, int min_tris,
                  rt_bvh_node** out_nodes, int32_t* out_n_nodes);
 
+/* NON-PARITY fast mode (no counterpart in the reference, which stops at BVH_DEPTH 16 with mean splits,
+ * config.h:17): a binned-SAH BVH2 in the same node / triangle layout, leaves of at most leaf_tris triangles
+ * (<= 0: 2), depth at most max_depth (<= 0: 24 = the traversal stack of rt.h).  rt_upload_scene takes it like
+ * any other tree; results differ from the reference's tree only in visit counts and in which of two equally
+ * distant triangles wins. */
+int rt_bvh_build_sah(float* tris, size_t n_floats, int max_depth, int leaf_tris,
+                     rt_bvh_node** out_nodes, int32_t* out_n_nodes);
+
+/* Rebuild the BVH of an assembled scene in place (records reordered, light list refreshed).
+ * mode RT_BVH_REFERENCE: createBVH as rt_bvh_build (leaf_tris = BVH_NODE_MIN_TRIS); RT_BVH_SAH: as above. */
+enum { RT_BVH_REFERENCE = 0, RT_BVH_SAH = 1 };
+int rt_scene_rebuild_bvh(rt_host_scene* s, int mode, int max_depth, int leaf_tris);
+
 /* Model::loadMesh (model.h:47-178); returns malloc'ed records. Also accepts
  * "f v//n", "f v/t" and "f v" faces (the reference only reads "f v/t/n"). */
 int rt_obj_load(const char* path, const float translation[3], float scale, const float rotation[3],

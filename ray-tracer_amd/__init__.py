@@ -100,7 +100,7 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
-                 "rt_image_save_rgb8", "rt_host_free"]
+                 "rt_image_save_rgb8", "rt_host_free", "rt_bvh_build_sah", "rt_scene_rebuild_bvh"]
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -143,6 +143,7 @@ def scene_lib() -> C.CDLL:
         L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(_fp), _ip, _ip]
         L.rt_image_save.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int]
         L.rt_image_save_rgb8.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.rt_scene_rebuild_bvh.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.rt_host_free.argtypes = [C.c_void_p]
         L.rt_host_free.restype = None
         _scene_lib = L
@@ -234,6 +235,15 @@ class Scene:
                                               env_path.encode() if env_path else None, env_upsample,
                                               bvh_max_depth, bvh_min_tris, C.byref(out))
         return cls._check(rc, out)
+
+    def rebuild_bvh(self, mode: str = "sah", max_depth: int = 0, leaf_tris: int = 0) -> "Scene":
+        """In place: "reference" = createBVH (depth 16, min 4), "sah" = the non-parity fast mode (depth 24, leaves <= 2)."""
+        L = scene_lib()
+        if L.rt_scene_rebuild_bvh(self._h, {"reference": 0, "sah": 1}[mode], max_depth, leaf_tris):
+            raise RuntimeError("scene: " + L.rt_scene_last_error().decode())
+        if L.rt_scene_get_desc(self._h, C.byref(self.desc)):
+            raise RuntimeError(L.rt_scene_last_error().decode())
+        return self
 
     def close(self):
         if self._h:

@@ -4,7 +4,7 @@
 // everything is a command-line option.
 //
 //   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
-//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--stats]
+//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +17,7 @@
 
 static int usage() {
     fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
-                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--stats]\n");
+                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]\n");
     return 2;
 }
 
@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     std::string scene, asset_root, out = "output.png", env;
     int spp = -1, bounces = 6, W = 0, H = 0, device = 0;
     unsigned seed = 37811;
-    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, want_stats = false;
+    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
         else if (a == "--wavefront") wavefront = true;
         else if (a == "--lockstep") lockstep = true;
         else if (a == "--volume") volume = true;
+        else if (a == "--fast-bvh") fast_bvh = true;
         else if (a == "--raymarch") raymarch = true;
         else if (a == "--stats") want_stats = true;
         else return usage();
@@ -58,6 +59,10 @@ int main(int argc, char** argv) {
     }
     rt_scene_desc desc;
     rt_camera cam;
+    if (fast_bvh && rt_scene_rebuild_bvh(hs, RT_BVH_SAH, 0, 0) != RT_OK) {  // non-parity fast mode
+        fprintf(stderr, "rebuild: %s\n", rt_scene_last_error());
+        return 1;
+    }
     rt_scene_get_desc(hs, &desc);
     rt_scene_get_camera(hs, &cam);
     printf("Number of triangles: %zu, BVH nodes: %d, materials: %zu\n", desc.n_tri_floats / RT_TRI_FLOATS, desc.n_nodes, desc.n_mats);

@@ -466,6 +466,40 @@ struct TmpNode {
     int depth = 0;
 };
 
+// Output stage shared by the builders: nodes are in creation order = BFS order, A before B (BFSIndex,
+// BVHcreator.cpp:41-61); triangles are rewritten leaf by leaf in that order (populateBVHNodes :209-237).
+int finish_bvh(const std::vector<TmpNode>& nodes, const std::vector<uint32_t>& ids, float* tris, size_t n_floats,
+               std::vector<rt_bvh_node>& out, int* out_depth) {
+    StageTimer tm_out("bvh: numbering + reorder");
+    out.resize(nodes.size());
+    int offs = 0, deepest_leaf = 0;
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const TmpNode& n = nodes[k];
+        rt_bvh_node& o = out[k];
+        for (int c = 0; c < 3; c++) { o.bbox_min[c] = n.mn[c]; o.bbox_max[c] = n.mx[c]; }
+        o.child_a = n.a;
+        o.child_b = n.b;
+        o.tri_offs = offs;
+        o.tri_len = n.a < 0 ? (int)(n.end - n.begin) * RT_TRI_FLOATS : 0;
+        offs += o.tri_len;
+        if (n.a < 0) deepest_leaf = std::max(deepest_leaf, n.depth);
+    }
+    std::unique_ptr<float[]> newtris(new float[std::max<size_t>(n_floats, 1)]);  // (not zero-filled: every float is written below)
+    parallel_for(nodes.size(), 64, [&](size_t k) {
+        const TmpNode& n = nodes[k];
+        if (n.a >= 0) return;
+        float* dst = &newtris[(size_t)out[k].tri_offs];
+        for (uint32_t i = n.begin; i < n.end; i++, dst += RT_TRI_FLOATS)
+            memcpy(dst, tris + (size_t)ids[i] * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
+    });
+    if (n_floats) {
+        const size_t cp = (size_t)1 << 22, nch = (n_floats + cp - 1) / cp;
+        parallel_for(nch, 1, [&](size_t c) { memcpy(tris + c * cp, &newtris[c * cp], std::min(cp, n_floats - c * cp) * sizeof(float)); });
+    }
+    if (out_depth) *out_depth = deepest_leaf;
+    return RT_OK;
+}
+
 // createBVH, BVHcreator.cpp:240-256 (createInitialNode :187-205, splitRecursive :173-184, splitNode :86-170,
 // BFSIndex :41-61, populateBVHNodes :209-237) -- same tree, same numbering, same triangle order, built level by
 // level instead of recursively:
@@ -593,35 +627,153 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
         for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
     }
     delete tm_split;
-    StageTimer tm_out("bvh: numbering + reorder");
-    // creation order is BFS order, A before B (BFSIndex :41-61); triangles leaf by leaf in that order
-    out.resize(nodes.size());
-    std::vector<size_t> src_begin(nodes.size());
-    int offs = 0;
-    for (size_t k = 0; k < nodes.size(); k++) {
-        const TmpNode& n = nodes[k];
-        rt_bvh_node& o = out[k];
-        for (int c = 0; c < 3; c++) { o.bbox_min[c] = n.mn[c]; o.bbox_max[c] = n.mx[c]; }
-        o.child_a = n.a;
-        o.child_b = n.b;
-        o.tri_offs = offs;
-        o.tri_len = n.a < 0 ? (int)(n.end - n.begin) * RT_TRI_FLOATS : 0;
-        offs += o.tri_len;
-    }
-    std::unique_ptr<float[]> newtris(new float[std::max<size_t>(n_floats, 1)]);  // (not zero-filled: every float is written below)
-    parallel_for(nodes.size(), 64, [&](size_t k) {
-        const TmpNode& n = nodes[k];
-        if (n.a >= 0) return;
-        float* dst = &newtris[(size_t)out[k].tri_offs];
-        for (uint32_t i = n.begin; i < n.end; i++, dst += RT_TRI_FLOATS)
-            memcpy(dst, tris + (size_t)ids[i] * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
+    return finish_bvh(nodes, ids, tris, n_floats, out, out_depth);
+}
+
+// NON-PARITY fast mode: a binned-SAH BVH2 in the same node / triangle layout, leaves of at most
+// `leaf_tris` triangles, depth capped at `max_depth` (the traversal stack holds RT_STACK_ENTRIES).  The kernels and the
+// oracle walk whatever tree the scene carries, so they still agree with each other bit for bit; what changes against
+// the reference is the tree (visit counts, and which of two equally distant triangles wins).
+int build_bvh_sah(float* tris, size_t n_floats, int max_depth, int leaf_tris, std::vector<rt_bvh_node>& out, int* out_depth) {
+    if (n_floats % RT_TRI_FLOATS != 0) return fail("triangle array length is not a multiple of 25");
+    const size_t ntri = n_floats / RT_TRI_FLOATS;
+    if (ntri > 0x7fffffffu / RT_TRI_FLOATS) return fail("too many triangles for int32 float offsets");
+    leaf_tris = std::max(leaf_tris, 1);
+    std::vector<float> cen(ntri * 3), tbox(ntri * 6);
+    std::vector<uint32_t> ids(ntri);
+    parallel_for(ntri, 1 << 16, [&](size_t i) {
+        const float* t = tris + i * RT_TRI_FLOATS;
+        float* bx = &tbox[i * 6];
+        for (int c = 0; c < 3; c++) {
+            bx[c] = fminf(fminf(t[c], t[3 + c]), t[6 + c]);
+            bx[3 + c] = fmaxf(fmaxf(t[c], t[3 + c]), t[6 + c]);
+            cen[i * 3 + c] = 0.5f * (bx[c] + bx[3 + c]);
+        }
+        ids[i] = (uint32_t)i;
     });
-    if (n_floats) {
-        const size_t cp = (size_t)1 << 22, nch = (n_floats + cp - 1) / cp;
-        parallel_for(nch, 1, [&](size_t c) { memcpy(tris + c * cp, &newtris[c * cp], std::min(cp, n_floats - c * cp) * sizeof(float)); });
+    auto range_box = [&](uint32_t b, uint32_t e, float* mn, float* mx) {
+        for (int c = 0; c < 3; c++) { mn[c] = 1e12f; mx[c] = -1e12f; }  // the reference's empty box
+        for (uint32_t i = b; i < e; i++) {
+            const float* bx = &tbox[(size_t)ids[i] * 6];
+            for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], bx[c]); mx[c] = fmaxf(mx[c], bx[3 + c]); }
+        }
+    };
+    auto half_area = [](const float* mn, const float* mx) {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<TmpNode> nodes(1);
+    nodes[0].begin = 0;
+    nodes[0].end = (uint32_t)ntri;
+    range_box(0, (uint32_t)ntri, nodes[0].mn, nodes[0].mx);
+    StageTimer tm("bvh (sah): splits");
+    std::vector<int> level{0}, splitting;
+    std::vector<uint32_t> mids;
+    while (!level.empty()) {
+        splitting.clear();
+        for (int ni : level) {
+            const TmpNode& n = nodes[ni];
+            if (n.depth >= max_depth || (int)(n.end - n.begin) <= leaf_tris) continue;
+            splitting.push_back(ni);
+        }
+        mids.assign(splitting.size(), 0);
+        auto choose = [&](size_t k) {  // partitions ids[begin, end) and records the split position
+            const TmpNode& n = nodes[splitting[k]];
+            const uint32_t b = n.begin, e = n.end, cnt = e - b;
+            float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
+            for (uint32_t i = b; i < e; i++)
+                for (int c = 0; c < 3; c++) {
+                    cmn[c] = fminf(cmn[c], cen[(size_t)ids[i] * 3 + c]);
+                    cmx[c] = fmaxf(cmx[c], cen[(size_t)ids[i] * 3 + c]);
+                }
+            // depth budget: once the remaining levels only just suffice for a balanced tree, split at the median
+            int need = 0;
+            while (((size_t)leaf_tris << need) < cnt) need++;
+            const bool forced_median = need >= max_depth - n.depth;
+            int best_axis = -1, best_bin = -1;
+            constexpr int NB = 16;
+            if (!forced_median) {
+                float best_cost = (float)cnt * half_area(n.mn, n.mx);  // cost of not splitting (x traversal weight 1)
+                for (int axis = 0; axis < 3; axis++) {
+                    const float w = cmx[axis] - cmn[axis];
+                    if (!(w > 0.0f)) continue;
+                    uint32_t bc[NB] = {0};
+                    float bmn[NB][3], bmx[NB][3];
+                    for (int j = 0; j < NB; j++)
+                        for (int c = 0; c < 3; c++) { bmn[j][c] = 1e30f; bmx[j][c] = -1e30f; }
+                    const float scale = (float)NB / w;
+                    for (uint32_t i = b; i < e; i++) {
+                        const uint32_t t = ids[i];
+                        int j = (int)((cen[(size_t)t * 3 + axis] - cmn[axis]) * scale);
+                        j = std::min(std::max(j, 0), NB - 1);
+                        bc[j]++;
+                        const float* bx = &tbox[(size_t)t * 6];
+                        for (int c = 0; c < 3; c++) { bmn[j][c] = fminf(bmn[j][c], bx[c]); bmx[j][c] = fmaxf(bmx[j][c], bx[3 + c]); }
+                    }
+                    float ra[NB];  // half area of bins j..NB-1
+                    uint32_t rc[NB];
+                    float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+                    uint32_t cc = 0;
+                    for (int j = NB - 1; j >= 0; j--) {
+                        for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], bmn[j][c]); mx[c] = fmaxf(mx[c], bmx[j][c]); }
+                        cc += bc[j];
+                        ra[j] = cc ? half_area(mn, mx) : 0.0f;
+                        rc[j] = cc;
+                    }
+                    for (int c = 0; c < 3; c++) { mn[c] = 1e30f; mx[c] = -1e30f; }
+                    cc = 0;
+                    for (int j = 0; j < NB - 1; j++) {  // split after bin j
+                        for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], bmn[j][c]); mx[c] = fmaxf(mx[c], bmx[j][c]); }
+                        cc += bc[j];
+                        if (cc == 0 || rc[j + 1] == 0) continue;
+                        const float cost = half_area(n.mn, n.mx) * 1.0f + (float)cc * half_area(mn, mx) + (float)rc[j + 1] * ra[j + 1];
+                        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = j; }
+                    }
+                }
+            }
+            uint32_t mid;
+            if (best_axis >= 0) {
+                const float w = cmx[best_axis] - cmn[best_axis], scale = (float)NB / w;
+                const float lo = cmn[best_axis];
+                uint32_t* first = &ids[b];
+                uint32_t* m = std::partition(first, first + cnt, [&](uint32_t t) {
+                    int j = (int)((cen[(size_t)t * 3 + best_axis] - lo) * scale);
+                    j = std::min(std::max(j, 0), NB - 1);
+                    return j <= best_bin;
+                });
+                mid = b + (uint32_t)(m - first);
+            } else {  // median along the widest centroid axis (or no SAH gain on a node that must still shrink)
+                int axis = 0;
+                if (cmx[1] - cmn[1] > cmx[axis] - cmn[axis]) axis = 1;
+                if (cmx[2] - cmn[2] > cmx[axis] - cmn[axis]) axis = 2;
+                mid = b + cnt / 2;
+                std::nth_element(&ids[b], &ids[mid], &ids[b] + cnt, [&](uint32_t x, uint32_t y) {
+                    const float cx = cen[(size_t)x * 3 + axis], cy = cen[(size_t)y * 3 + axis];
+                    return cx < cy || (cx == cy && x < y);
+                });
+            }
+            mids[k] = mid;
+        };
+        if (splitting.size() < (size_t)host_threads() * 2) for (size_t k = 0; k < splitting.size(); k++) choose(k);
+        else parallel_for(splitting.size(), 1, choose);
+        const size_t first_child = nodes.size();
+        nodes.resize(first_child + 2 * splitting.size());
+        parallel_for(splitting.size(), 4, [&](size_t k) {
+            TmpNode& n = nodes[splitting[k]];
+            n.a = (int)(first_child + 2 * k);
+            n.b = n.a + 1;
+            TmpNode& A = nodes[n.a];
+            TmpNode& B = nodes[n.b];
+            A.depth = B.depth = n.depth + 1;
+            A.begin = n.begin; A.end = mids[k];
+            B.begin = mids[k]; B.end = n.end;
+            range_box(A.begin, A.end, A.mn, A.mx);
+            range_box(B.begin, B.end, B.mn, B.mx);
+        });
+        level.clear();
+        for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
     }
-    if (out_depth) *out_depth = deepest_leaf;
-    return RT_OK;
+    return finish_bvh(nodes, ids, tris, n_floats, out, out_depth);
 }
 
 // ------------------------------------------------------------------ scene DSL
@@ -923,6 +1075,38 @@ int rt_bvh_build(float* tris, size_t n_floats, int max_depth, int min_tris, rt_b
     memcpy(p, nodes.data(), nodes.size() * sizeof(rt_bvh_node));
     *out_nodes = p;
     *out_n_nodes = (int32_t)nodes.size();
+    return RT_OK;
+}
+
+int rt_bvh_build_sah(float* tris, size_t n_floats, int max_depth, int leaf_tris, rt_bvh_node** out_nodes,
+                     int32_t* out_n_nodes) {
+    if (!tris && n_floats) return fail("null triangle array");
+    if (!out_nodes || !out_n_nodes) return fail("null output");
+    if (max_depth <= 0) max_depth = 24;
+    if (leaf_tris <= 0) leaf_tris = 2;
+    std::vector<rt_bvh_node> nodes;
+    int rc = build_bvh_sah(tris, n_floats, max_depth, leaf_tris, nodes, nullptr);
+    if (rc != RT_OK) return rc;
+    rt_bvh_node* p = (rt_bvh_node*)malloc(nodes.size() * sizeof(rt_bvh_node));
+    if (!p) return fail("out of memory");
+    memcpy(p, nodes.data(), nodes.size() * sizeof(rt_bvh_node));
+    *out_nodes = p;
+    *out_n_nodes = (int32_t)nodes.size();
+    return RT_OK;
+}
+
+int rt_scene_rebuild_bvh(rt_host_scene* s, int mode, int max_depth, int leaf_tris) {
+    if (!s) return fail("null scene");
+    if (mode != RT_BVH_REFERENCE && mode != RT_BVH_SAH) return fail("unknown BVH mode");
+    const size_t prefix = s->n_spheres > 0 ? 1 + 5 * (size_t)s->n_spheres : 0;
+    float* rec = s->tris.data() + prefix;
+    const size_t n = s->tris.size() - prefix;
+    for (int32_t off : s->lights) rec[(size_t)off + 24] += 1000.0f;  // the marker extract_lights looks for (sceneParser.cpp:408-410)
+    int rc;
+    if (mode == RT_BVH_SAH) rc = build_bvh_sah(rec, n, max_depth > 0 ? max_depth : 24, leaf_tris > 0 ? leaf_tris : 2, s->nodes, &s->bvh_depth);
+    else rc = build_bvh(rec, n, max_depth > 0 ? max_depth : 16, leaf_tris > 0 ? leaf_tris : 4, s->nodes, &s->bvh_depth);
+    if (rc != RT_OK) return rc;
+    extract_lights(rec, n, s->lights);
     return RT_OK;
 }
 

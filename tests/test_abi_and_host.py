@@ -325,6 +325,71 @@ def test_bvh_structure_invariants(rt):
     assert sorted(map(bytes, newtris)) == sorted(map(bytes, tris))
 
 
+def build_sah(rt, tris, depth=24, leaf=2):
+    L = rt.scene_lib()
+    t = np.ascontiguousarray(tris, np.float32).copy()
+    nodes = C.POINTER(rt.BvhNode)()
+    n = C.c_int32()
+    L.rt_bvh_build_sah.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(rt.BvhNode)),
+                                   C.POINTER(C.c_int32)]
+    assert L.rt_bvh_build_sah(t.ctypes.data_as(C.POINTER(C.c_float)), t.size, depth, leaf, C.byref(nodes), C.byref(n)) == 0
+    out = [(tuple(nodes[i].bbox_min), tuple(nodes[i].bbox_max), nodes[i].child_a, nodes[i].child_b,
+            nodes[i].tri_offs, nodes[i].tri_len) for i in range(n.value)]
+    L.rt_host_free(nodes)
+    return out, t.reshape(-1, 25)
+
+
+@pytest.mark.parametrize("n,depth,leaf", [(20000, 24, 2), (3000, 6, 2), (500, 24, 1), (1, 24, 2), (0, 24, 2)])
+def test_sah_tree_invariants(rt, n, depth, leaf):
+    """The non-parity fast tree (rt_bvh_build_sah) is a valid tree of the same layout: BFS numbering, leaves tile the
+    triangle array, boxes bound, depth within the cap, leaves small wherever the depth budget allowed it."""
+    tris = random_soup(n, 21) if n else np.zeros((0, 25), np.float32)
+    if n >= 500:
+        tris[100:140, 0:9] = tris[100, 0:9]          # 40 identical triangles: no split plane separates their centroids
+    nodes, newtris = build_sah(rt, tris, depth, leaf)
+    seen, dep = 1, {0: 0}
+    for i, (mn, mx, a, b, offs, ln) in enumerate(nodes):
+        if a != -1:
+            assert a == seen and b == seen + 1 and ln == 0
+            seen += 2
+            dep[a] = dep[b] = dep[i] + 1
+        else:
+            assert b == -1
+    assert seen == len(nodes) and max(dep.values()) <= depth
+    leafs = [(i, offs, ln) for i, (_, _, a, _, offs, ln) in enumerate(nodes) if a == -1]
+    assert leafs[0][1] == 0 and all(leafs[k][1] + leafs[k][2] == leafs[k + 1][1] for k in range(len(leafs) - 1))
+    assert leafs[-1][1] + leafs[-1][2] == tris.size
+    for i, offs, ln in leafs:
+        if ln:
+            v = newtris[offs // 25:(offs + ln) // 25, 0:9].reshape(-1, 3)
+            assert np.all(v >= np.float32(nodes[i][0])) and np.all(v <= np.float32(nodes[i][1]))
+        assert ln // 25 <= leaf or dep[i] == depth
+    for i, (mn, mx, a, b, offs, ln) in enumerate(nodes):         # inner boxes contain their children's
+        if a != -1:
+            for ch in (a, b):
+                if nodes[ch][5] or nodes[ch][2] != -1:
+                    assert np.all(np.float32(nodes[ch][0]) >= np.float32(mn)) and np.all(np.float32(nodes[ch][1]) <= np.float32(mx))
+    assert sorted(map(bytes, newtris)) == sorted(map(bytes, tris))
+    if n == 20000:
+        assert max(ln for _, _, ln in leafs) // 25 <= 2 and len(nodes) > 2 * n // 3
+
+
+def test_scene_rebuild_keeps_lights_and_reference_tree(rt, scenes):
+    sc = rt.Scene.load("scene2_is.txt")
+    lights0 = sorted(bytes(sc.tris()[o // 25]) for o in np.ctypeslib.as_array(sc.desc.light_tris, shape=(sc.desc.n_light_tris,)))
+    n0 = sc.desc.n_nodes
+    sc.rebuild_bvh("sah")
+    assert sc.desc.n_nodes > n0 and sc.desc.n_light_tris == len(lights0)
+    lt = np.ctypeslib.as_array(sc.desc.light_tris, shape=(sc.desc.n_light_tris,))
+    assert np.all(np.diff(lt) > 0) and np.all(lt % 25 == 0)
+    assert sorted(bytes(sc.tris()[o // 25]) for o in lt) == lights0            # the same triangles, new offsets
+    assert np.all(sc.tris()[:, 24] < 1000)                                      # markers removed again
+    ref = scenes("scene.txt")
+    a = rt.Scene.load("scene.txt")
+    a.rebuild_bvh("reference")                                                  # same records, same order -> the same tree
+    assert a.desc.n_nodes == ref.desc.n_nodes and np.array_equal(a.tris(), ref.tris())
+
+
 def test_bvh_depth_cap_gives_fat_leaves(rt):
     tris = random_soup(3000, 5)
     nodes, _ = build(rt, tris, depth=4)
