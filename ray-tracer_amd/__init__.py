@@ -108,7 +108,7 @@ _ip = C.POINTER(C.c_int32)
 
 def _load(name: str) -> C.CDLL:
     path = os.path.join(LIB_DIR, name)
-    if name == "librt_amd.so" and os.environ.get("RT_AMD_LIB"):  # A/B builds of the HIP core (tools/ab_bench.sh)
+    if name == "librt_amd.so" and os.environ.get("RT_AMD_LIB"):  # A/B builds of the HIP core (tools/ab_build.sh)
         path = os.environ["RT_AMD_LIB"]
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `make` (or __graft_entry__.build()) first; "

@@ -3,20 +3,19 @@
 // Replaces the render call of the reference: uploads src/main.cu:418-460, kernel
 // render2 src/main.cu:155-407 (launch :472-482), readback :500-501.
 //
-// Kernel design (gfx950):
-//  * rt_render_kernel -- wavefront-persistent: a grid sized to the chip's residency,
-//    256-thread blocks = 4 independent waves.  Each wave pulls 8x8-pixel tiles from a
-//    global atomic counter; lane = pixel.  Inside a tile a lane runs a path state
-//    machine with REGENERATION: when its path ends it starts its next sample in the
-//    same iteration, so every iteration of the wave loop is "all lanes trace one ray,
-//    all lanes shade one hit" instead of the reference's nested per-thread loops.
-//    Traversal stack: per-lane short stack in LDS ([entry][lane] => conflict-free).
-//    Node/triangle/material fetches are 16-byte vector loads from the 64/48-byte
-//    records of rt_device.h.
-//  * one lane owns one pixel for the whole call => accumulation is a plain
-//    read-modify-write (no float atomics, bit-reproducible).
-//  * raw-sum accumulators + separate resolve kernel (needed for RCCL sum-reduce and
-//    progressive batches).
+// Kernel design (gfx950), details at each kernel and in DESIGN.md section 4:
+//  * rt_render_paths_kernel (default) -- persistent 1024-thread blocks, one per CU, sharing an LDS copy of the top
+//    of the tree.  The unit of work is one PATH (pixel, sample); a lane is traversing, or waits for a vertex pass,
+//    and every iteration the wave votes and runs ONE kind of step (vertex pass / triangle test / inner-node
+//    visit / whole-wave test of a big leaf) for the lanes that wait for it.  Per-path radiance goes to a buffer,
+//    rt_sum_samples_kernel adds it per pixel in sample order => bit-reproducible sums, no float atomics.
+//  * rt_render_kernel (RT_F_LOCKSTEP) -- a wave owns an 8x8 tile, lane = pixel, "trace one ray, shade one hit"
+//    in lock step with path regeneration.
+//  * rt_logic_kernel + rt_trace_kernel (RT_F_WAVEFRONT) -- one global ray queue per bounce; the trace kernel is
+//    also what rt_trace_rays runs.
+//  * Traversal stack: per-lane short stack in LDS ([entry][lane] => conflict-free).  Node / triangle / material
+//    fetches are 16-byte vector loads from the 64/48-byte records of rt_device.h.
+//  * raw-sum accumulators + separate resolve kernels (needed for RCCL sum-reduce and progressive batches).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -733,37 +732,21 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
     // leave at once.
     const unsigned int n_waves = gridDim.x * RT_TRACE_WAVES;
     const unsigned int gw = blockIdx.x * RT_TRACE_WAVES + wave;
-#ifndef RT_DIST
-#define RT_DIST 0
-#endif
-#ifndef RT_CHUNK_MAX
-#define RT_CHUNK_MAX 512
-#endif
     unsigned int chunk = 64;
-#if RT_DIST == 0
-    while (chunk < RT_CHUNK_MAX && (unsigned long long)chunk * n_waves * 2 <= n_rays) chunk *= 2;
-#endif
+    while (chunk < 512 && (unsigned long long)chunk * n_waves * 2 <= n_rays) chunk *= 2;
     unsigned int next = gw * chunk;                                  // wave-uniform: next ray of the local chunk
     unsigned int end = next + chunk < n_rays ? next + chunk : n_rays;  // wave-uniform: end of the local chunk
     bool exhausted = next >= n_rays;
     if (exhausted) next = end = 0;
-#if RT_DIST == 1
-    unsigned int my_chunk = gw;  // static interleave: chunks gw, gw + n_waves, ...
-#endif
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const int n_idle = __popcll(idle);
         if (!exhausted && (n_idle >= RT_REFILL_MIN || n_idle == 64)) {
             if (next >= end) {  // local chunk used up: take another one
-#if RT_DIST == 1
-                my_chunk += n_waves;
-                const unsigned long long start = (unsigned long long)my_chunk * chunk;
-#else
                 unsigned int c = 0;
                 if (lane == 0) c = atomicAdd(cursor, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
                 const unsigned long long start = ((unsigned long long)n_waves + c) * chunk;
-#endif
                 if (start >= n_rays) exhausted = true;
                 else { next = (unsigned int)start; end = next + chunk < n_rays ? next + chunk : n_rays; }
             }

@@ -18,11 +18,9 @@ namespace rtd {
 
 // ------------------------------------------------------------------ layouts in HBM
 //
-// ITEM STREAM (64 B = 4 x float4 per item): inner nodes and triangles live in ONE array so that a
-// wave advances every lane by one traversal step -- an inner-node visit or one triangle test --
-// with the same four 16-byte loads (the vector-memory pipeline, not the VALU, is what bounds
-// this kernel: its cost is per wave-instruction, so every load must serve as many lanes as
-// possible).  Items [0, n_inner) are the INNER nodes of the reference BVH in its BFS order,
+// ITEM STREAM (64 B = 4 x float4 per item): inner nodes and triangles live in ONE array with ONE index
+// space, so a traversal cursor is a single int and a step -- an inner-node visit or one triangle test
+// -- is a few 16-byte loads at 64 * cursor.  Items [0, n_inner) are the INNER nodes of the reference BVH in its BFS order,
 // items [n_inner, n_inner + n_tris) the triangles in the reference's (leaf-contiguous) order.
 //   inner item: both child boxes + both child entries (one 64-B fetch per inner visit instead
 //               of the reference's two 40-B child fetches, main.cu:268-269)
@@ -606,7 +604,7 @@ __device__ __forceinline__ int trav_spheres(const Scene& sc, Trav& t, f3& sPos) 
     return hitSphere;
 }
 
-// Whole query for one lane (megakernel mode): steps until done.
+// Whole query for one lane (lock-step fused kernel): steps until done.
 template <bool STATS>
 __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool use_bvh, int* stk, int& hitTri,
                                               float& minD2, f3& hitPos, Counters& cn, int n_cached = 0) {
@@ -614,24 +612,13 @@ __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool 
     if (STATS) cn.rays++;
     trav_begin(sc, t, o, d);
     if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
-#ifndef RT_MEGA_WHILE
-#define RT_MEGA_WHILE 0  // measured slower than one mixed step per iteration (profiles/r01_ab_megakernel.txt)
-#endif
-#if RT_MEGA_WHILE
-    // "while-while": all lanes first walk inner nodes until each holds a triangle (or is done), then
-    // the wave tests triangles until each lane is back at an inner node.  Same per-lane visit
-    // order; measured faster than mixing both kinds in every iteration when lanes cannot be refilled.
-    while (t.cur != RT_TRAV_DONE) {
-        while (t.cur >= 0 && t.cur < sc.n_inner) trav_step<STATS>(sc, t, stk, cn, n_cached);
-        while (t.cur >= sc.n_inner || t.cur == RT_TRAV_EMPTY) trav_step<STATS>(sc, t, stk, cn, n_cached);
-    }
-#else
+    // one mixed step per iteration (a "while-while" split of inner and triangle steps measured slower in lock step,
+    // profiles/r01_ab_megakernel.txt)
     while (t.cur != RT_TRAV_DONE) {
         RT_PROF_COUNT(cn, 0, 1);
         RT_PROF_LANE(cn, 1);
         trav_step<STATS>(sc, t, stk, cn, n_cached);
     }
-#endif
     hitTri = t.hitTri;
     minD2 = t.minD2;
     hitPos = t.hitTri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
