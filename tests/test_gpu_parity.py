@@ -106,6 +106,58 @@ def test_sah_fast_mode_agrees_with_oracle_and_reference_tree(ob, rt, gpu, name):
     assert mean_rel < 0.02                                    # (scene.txt: identical; with lights: other picks, same mean)
 
 
+def random_scene(rt, seed):
+    """A random triangle soup with every material type, a texture, importance-sampled lights, clustered so that the
+    BVH gets leaves of all sizes (incl. empty ones and, with a shallow tree, leaves big enough for the whole-wave test)."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(40, 1500))
+    c = rng.normal(0, 1.5, (n, 1, 3)) + np.array([0, 0, -6.0])
+    v = c + rng.normal(0, rng.choice([0.05, 0.3, 1.0]), (n, 3, 3))
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = v.reshape(n, 9)
+    nr = rng.normal(0, 1, (n, 3, 3)); nr /= np.linalg.norm(nr, axis=2, keepdims=True)
+    t[:, 9:18] = nr.reshape(n, 9)
+    t[:, 18:24] = rng.uniform(0, 0.999, (n, 6))
+    tex = rng.uniform(0, 1, (32, 16, 3)).astype(np.float32)             # env 0x0 here: texture pool = one 16x32 image
+    mats = []
+    for ty in [0, 1, 2, 3, 3, 4, 5, 6]:
+        m = rt.Material(); m.type = ty; m.color = int(rng.integers(0, 1 << 24)); m.p1 = float(rng.uniform(0.1, 1.5)); m.p2 = float(rng.uniform(0, 0.5))
+        m.image_offset[:] = [-1, -1, -1]
+        mats.append(m)
+    mats[4].image_offset[0] = 0; mats[4].image_width = 16; mats[4].image_height = 32
+    mid = rng.integers(0, len(mats), n)
+    t[:, 24] = mid + 0.001
+    lights = rng.random(n) < 0.03
+    t[lights, 24] = 1 + 1000 + 0.001                                      # emissive + importance sampled
+    depth = int(rng.choice([3, 6, 16]))
+    sc = rt.Scene.from_records(t, mats, textures=tex, bvh_max_depth=depth, bvh_min_tris=int(rng.choice([1, 4, 9])))
+    return sc, rng
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scenes_all_schedules_match_oracle(ob, rt, gpu, seed):
+    sc, rng = random_scene(rt, 1000 + seed)
+    gpu.upload(sc)
+    flags = rt.F_BVH | int(rng.choice([0, rt.F_ANTIALIAS])) | int(rng.choice([0, rt.F_DEFOCUS])) | rt.F_STATS
+    p = rt.default_params(sc.camera, spp=int(rng.integers(1, 6)), width=int(rng.integers(9, 90)), height=int(rng.integers(9, 70)),
+                          max_bounces=int(rng.integers(1, 9)), flags=flags)
+    p.cam.aperture = float(rng.choice([0.0, 0.08])); p.cam.focus_distance = 5.0
+    p.cam.vel[:] = [float(rng.choice([0, 0.3])), 0, 0]
+    p.seed = int(rng.integers(0, 1 << 31))
+    p.sample_begin = int(rng.integers(0, 1000))
+    o, ost = ob.render(sc, p, n_threads=8)
+    for mode in ("megakernel", "lockstep", "wavefront"):
+        q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
+        gpu.reset(); st = gpu.render(q)
+        assert np.array_equal(gpu.readback(), o), (seed, mode)
+        assert [st.paths, st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits, st.texel_fetches, st.light_tests] == \
+               [ost.paths, ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits, ost.texel_fetches, ost.light_tests], (seed, mode)
+    q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.F_VOLUME     # the type-6 triangles become a medium
+    ov, _ = ob.render(sc, q, n_threads=8)
+    gpu.reset(); gpu.render(q)
+    assert np.array_equal(gpu.readback(), ov), seed
+
+
 def image_metrics(a, b):
     ya, yb = a @ LUMA, b @ LUMA
     mean_rel = abs(float(ya.mean()) - float(yb.mean())) / float(yb.mean())
