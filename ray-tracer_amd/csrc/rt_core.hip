@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     t.oxy = t.ixy = (v2f){0.f, 0.f};
     t.oz = t.iz = 0.f;
     t.d = mk(0.f, 0.f, 0.f);
+    t.axis_parallel = false;
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
     f3 ro = mk(0.f, 0.f, 0.f);  // origin of the ray that starts in the current vertex pass
     t.cur = RT_LANE_NEW;

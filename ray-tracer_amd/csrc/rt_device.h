@@ -340,6 +340,7 @@ struct Trav {
     v2f oxy, ixy;
     float oz, iz;
     f3 d;
+    bool axis_parallel;  // some 1/d component is not finite: the box test needs its inside shortcut (aabb_distance_nb)
     __device__ __forceinline__ f3 o() const { return mk(oxy.x, oxy.y, oz); }
     __device__ __forceinline__ f3 inv() const { return mk(ixy.x, ixy.y, iz); }
     int cur;      // item to visit next (inner node or triangle), RT_TRAV_EMPTY, or RT_TRAV_DONE
@@ -359,6 +360,7 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d,
     t.d = d;
     t.ixy = (v2f){1.0f / d.x, 1.0f / d.y};
     t.iz = 1.0f / d.z;
+    t.axis_parallel = !(fabsf(t.ixy.x) < INFINITY && fabsf(t.ixy.y) < INFINITY && fabsf(t.iz) < INFINITY);
     t.sp = 0;
     t.hitTri = -1;
     t.minD2 = minD2_0;  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
@@ -419,9 +421,14 @@ __device__ __forceinline__ float aabb_distance_pk(v2f oxy, v2f ozz, v2f ixy, v2f
 #ifndef RT_INNER_PK
 #define RT_INNER_PK 0  // 1 = the packed two-float form below: fewer instructions, slower (v_pk_*_f32 issues at half rate)
 #endif
+// INSIDE = false drops the inside test.  Allowed when 1/d is finite on every axis: an origin inside the box then has
+// a <= 0 <= b per axis, so every slab gives min(t1, t2) <= 0 <= max(t1, t2) (no 0 * inf), tmin stays (+-)0 and
+// tmax >= 0: the slab test itself returns (+-)0, whose square is the +0 of the shortcut.  Only a ray with a zero (or
+// denormal) direction component can differ, and carries Trav::axis_parallel.
+template <bool INSIDE = true>
 __device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) {  // scalar form of aabb_distance_pk
     const f3 a = mn - o, b = mx - o;
-    const bool inside = fmaxf(fmaxf(a.x, a.y), a.z) <= 0.0f && fminf(fminf(b.x, b.y), b.z) >= 0.0f;
+    const bool inside = INSIDE && fmaxf(fmaxf(a.x, a.y), a.z) <= 0.0f && fminf(fminf(b.x, b.y), b.z) >= 0.0f;
     const f3 t1 = a * inv, t2 = b * inv;
     float tmin = fmaxf(0.0f, fminf(t1.x, t2.x));
     float tmax = fminf(1e13f, fmaxf(t1.x, t2.x));
@@ -442,8 +449,14 @@ __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, flo
     float dA = aabb_distance_pk(oxy, ozz, ixy, izz, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q2.x, q2.y});
     float dB = aabb_distance_pk(oxy, ozz, ixy, izz, (v2f){q1.x, q1.y}, (v2f){q1.z, q1.w}, (v2f){q2.z, q2.w});
 #else
-    float dA = aabb_distance_nb(t.o(), t.inv(), mk(q0.x, q0.y, q2.x), mk(q0.z, q0.w, q2.y));
-    float dB = aabb_distance_nb(t.o(), t.inv(), mk(q1.x, q1.y, q2.z), mk(q1.z, q1.w, q2.w));
+    float dA, dB;
+    if (__ballot(t.axis_parallel) == 0) {  // (wave-uniform: no lane of this step needs the inside test)
+        dA = aabb_distance_nb<false>(t.o(), t.inv(), mk(q0.x, q0.y, q2.x), mk(q0.z, q0.w, q2.y));
+        dB = aabb_distance_nb<false>(t.o(), t.inv(), mk(q1.x, q1.y, q2.z), mk(q1.z, q1.w, q2.w));
+    } else {
+        dA = aabb_distance_nb<true>(t.o(), t.inv(), mk(q0.x, q0.y, q2.x), mk(q0.z, q0.w, q2.y));
+        dB = aabb_distance_nb<true>(t.o(), t.inv(), mk(q1.x, q1.y, q2.z), mk(q1.z, q1.w, q2.w));
+    }
 #endif
     dA = dA * dA;
     dB = dB * dB;

@@ -67,6 +67,26 @@ def test_secondary_hit_ids_bit_exact(ob, rt, gpu, scenes, name):
     check_hits(ob, rt, gpu, sc, secondary_rays(sc, 16384, 7))
 
 
+@pytest.mark.parametrize("name", ["scene_cornellbox.txt", "scene.txt"])
+def test_axis_parallel_rays_keep_the_inside_shortcut(ob, rt, gpu, scenes, name):
+    """Rays with zero direction components (1/d = inf: 0 * inf in a slab when the origin lies on a box plane) starting
+    on node-box corners, faces and inside boxes: the traversal's fast box test (no inside shortcut) must not be used for
+    them, mixed in one wave with general rays -- ids, t, normals and visit counts as the oracle's."""
+    sc = scenes(name)
+    nodes = np.ctypeslib.as_array(C.cast(sc.desc.nodes, C.POINTER(C.c_float)), shape=(sc.desc.n_nodes, 10))
+    mn, mx = nodes[:, 0:3], nodes[:, 3:6]
+    ok = np.all(mn <= mx, axis=1)
+    mn, mx = mn[ok][:400], mx[ok][:400]
+    rng = np.random.default_rng(3)
+    org = np.concatenate([mn, mx, 0.5 * (mn + mx), np.stack([mn[:, 0], mx[:, 1], 0.5 * (mn[:, 2] + mx[:, 2])], 1)])
+    axes = np.float32([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0.6, 0.8, 0], [0, -0.6, 0.8],
+                       [1e-42, 0, -1]])                                   # (a denormal component: 1/d overflows too)
+    d = axes[rng.integers(0, len(axes), org.shape[0])]
+    rays = np.concatenate([np.concatenate([org, d], 1).astype(np.float32), secondary_rays(sc, 1024, 4)])
+    rays = rays[rng.permutation(rays.shape[0])]
+    check_hits(ob, rt, gpu, sc, rays)
+
+
 def test_brute_force_matches_bvh_and_oracle(ob, rt, gpu, scenes):
     sc = scenes("scene.txt")
     rays = secondary_rays(sc, 2048, 11)
