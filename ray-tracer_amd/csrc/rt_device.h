@@ -936,8 +936,13 @@ __device__ __forceinline__ long long env_index(f3 d, int W, int H) {
     float by = -pm::asin(d.y) / (2.0f * 3.14159f) + 0.5f;
     bx *= (float)W;
     by *= (float)H;
-    const int ix = (int)bx % W;
-    const int iy = (int)by % H;
+    int ix = (int)bx, iy = (int)by;
+    // `% W`, `% H` (main.cu:380-381) change nothing for 0 <= i < W: the two integer divisions run only if some lane
+    // of the wave is outside (atan2 = pi exactly, NaN directions)
+    if (__any((unsigned)ix >= (unsigned)W || (unsigned)iy >= (unsigned)H)) {
+        ix %= W;
+        iy %= H;
+    }
     return ((long long)iy * W + ix) * 3;
 }
 
