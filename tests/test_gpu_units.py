@@ -466,3 +466,32 @@ def test_full_hd_properties(rt, gpu, scenes):
         gpu.reset(); gpu.render(q)
         out[[y for y in range(H) if (y // 16) % 8 == r]] = gpu.readback()
     assert np.array_equal(out, a)                                           # 8-way tile-row gather == 1 GPU
+
+
+def test_config4_field_at_full_size(ob, rt, gpu):
+    """BASELINE config 4 at its real size: 628 dragons = 9 999 018 triangles in the reference's depth-16 tree (leaves of
+    ~150 triangles, tested by the whole wave in the path kernel), 3840x2160.  Size-independent properties: the path
+    kernel and the lock-step kernel (which walks the same leaves one triangle per lane-step) give the same image and
+    the same counters; an 8-way tile-row gather equals the single image; and on a crop the oracle agrees bit for bit."""
+    sc = rt.Scene.synth_field(628, env_path=os.path.join(rt.ASSET_DIR, "cape_hill_1k.hdr"), env_upsample=4)
+    assert sc.n_tris == 9999018 and sc.desc.n_nodes > 100000
+    gpu.upload(sc)
+    W, H = 3840, 2160
+    p = rt.default_params(sc.camera, spp=1, width=W, height=H, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
+    gpu.reset(); st = gpu.render(p); img = gpu.readback()
+    q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.F_LOCKSTEP
+    gpu.reset(); st_l = gpu.render(q)
+    assert np.array_equal(gpu.readback(), img)
+    assert (st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == \
+           (st_l.rays, st_l.inner_visits, st_l.leaf_visits, st_l.tri_tests, st_l.hits)
+    assert st.paths == W * H and st.tri_tests > 100 * st.rays and np.all(np.isfinite(img))
+    out = np.zeros_like(img)
+    for r in range(8):
+        b = rt.RenderParams.from_buffer_copy(p); b.band_rows, b.band_stride, b.band_index = 16, 8, r
+        gpu.reset(); gpu.render(b)
+        out[[y for y in range(H) if (y // 16) % 8 == r]] = gpu.readback()
+    assert np.array_equal(out, img)
+    c = rt.default_params(sc.camera, spp=2, width=96, height=54, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
+    gpu.reset(); st_c = gpu.render(c); crop = gpu.readback()
+    o, ost = ob.render(sc, c, n_threads=16)
+    assert np.array_equal(crop, o) and (st_c.rays, st_c.tri_tests) == (ost.rays, ost.tri_tests)
