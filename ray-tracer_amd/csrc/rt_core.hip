@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 
 // BIG: the scene has big leaves (Scene::tri_soa), tested by the whole wave.  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
 // (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
-template <bool STATS, bool BIG, bool EXTRA>
+template <bool STATS, bool BIG, bool EXTRA, bool COOP>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
@@ -278,9 +278,14 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             RT_PROF_COUNT(cn, 3, 1);
             if ((unsigned)(t.cur + 2) < 2u) RT_PROF_LANE(cn, 4);
             bool go = false;        // this lane holds a ray whose traversal starts in this pass
-            if (t.cur == RT_TRAV_DONE) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
+            PathState ray;
+            f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
+            bool alive = true;
+            const bool shading = t.cur == RT_TRAV_DONE;
+            LightQuery lq;
+            lq.pending = false;
+            if (shading) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
                 const uint32_t bb = (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2;
-                PathState ray;
                 ray.o = t.o();
                 ray.d = t.d;
                 ray.thr = thr;
@@ -288,8 +293,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 ray.ri = ri;
                 ray.volDensity = EXTRA ? volDensity : 0.0f;
                 ray.volColor = EXTRA ? volColor : mk(1.f, 1.f, 1.f);
-                f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
-                bool alive = true, handled = false;
+                bool handled = false;
                 // main.cu:338, 350 hand checkScatteredVolume the TRIANGLE hit position (zero without one), also for spheres
                 const f3 triPos = (volume && t.hitTri >= 0) ? t.hit_pos() : mk(0.f, 0.f, 0.f);
                 if (spheres_on) {
@@ -312,10 +316,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                             // scattered inside the volume: `continue`, main.cu:350-352
                         } else {
                             if (STATS) cn.hits++;
-                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn)) {  // main.cu:357-360
+                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn, COOP ? &lq : nullptr)) {  // main.cu:357-360
                                 e = ray.emission * ray.thr;
                                 alive = false;
-                            } else {
+                            } else if (!COOP || !lq.pending) {
                                 ray.d = normalize_keep(ray.d);  // main.cu:361
                             }
                         }
@@ -336,6 +340,15 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                         alive = false;
                     }
                 }
+            }
+            if (COOP && __ballot(lq.pending)) {  // material type 5 with many lights: its light loop, with the whole wave (rt_device.h)
+                const float pdf_light = wave_light_pdf<STATS>(sc, lq, cn);
+                if (lq.pending) {
+                    finish_type5(sc, ray, lq, pdf_light);
+                    ray.d = normalize_keep(ray.d);  // main.cu:361
+                }
+            }
+            if (shading) {
                 if (EXTRA) {
                     volDensity = ray.volDensity;
                     volColor = ray.volColor;
@@ -1319,7 +1332,14 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once
-    std::vector<float> lights((size_t)std::max(s->n_light_tris, 1) * 20, 0.f);
+    const int n_light_groups = (std::max(s->n_light_tris, 1) + 63) / 64;
+    const size_t light_box_off = (size_t)std::max(s->n_light_tris, 1) * 20;  // padded bounds per 64 lights behind the records
+    std::vector<float> lights(light_box_off + (size_t)n_light_groups * 8, 0.f);
+    for (int g = 0; g < n_light_groups; g++)
+        for (int k = 0; k < 3; k++) {
+            lights[light_box_off + (size_t)g * 8 + k] = 3e38f;
+            lights[light_box_off + (size_t)g * 8 + 4 + k] = -3e38f;
+        }
     for (int i = 0; i < s->n_light_tris; i++) {
         const int off = s->light_tris[i];
         if (off < 0 || off % RT_TRI_FLOATS || (size_t)off + RT_TRI_FLOATS > s->n_tri_floats)
@@ -1334,6 +1354,20 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         L[0] = p1.x; L[1] = p1.y; L[2] = p1.z; L[3] = e1.x; L[4] = e1.y; L[5] = e1.z;
         L[6] = e2.x; L[7] = e2.y; L[8] = e2.z; L[9] = nrm.x; L[10] = nrm.y; L[11] = nrm.z;
         L[12] = area; L[13] = p2.x; L[14] = p2.y; L[15] = p2.z; L[16] = p3.x; L[17] = p3.y; L[18] = p3.z; L[19] = 0.f;
+        float* B = &lights[light_box_off + (size_t)(i / 64) * 8];
+        for (int k = 0; k < 3; k++) {
+            B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
+            B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
+        }
+    }
+    for (int g = 0; g < n_light_groups && s->n_light_tris > 0; g++) {  // pad: the culling test must never say no wrongly
+        float* B = &lights[light_box_off + (size_t)g * 8];
+        float scale = 1.f;
+        for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(B[k]), std::fabs(B[4 + k])));
+        for (int k = 0; k < 3; k++) {
+            B[k] -= 1e-4f * scale;
+            B[4 + k] += 1e-4f * scale;
+        }
     }
 
     // ---- spheres
@@ -1373,6 +1407,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
+    sc.light_boxes = sc.lights + light_box_off / 4;
     sc.spheres = (const float4*)c->d_spheres;
     sc.tex = (const float*)c->d_tex;
     sc.n_tex = (long long)s->n_tex_floats;
@@ -1473,21 +1508,23 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
 }
 
 typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
-paths_fn paths_kernel_variant(bool stats, bool big, bool extra) {
-    static const paths_fn table[8] = {
-        rt_render_paths_kernel<false, false, false>, rt_render_paths_kernel<true, false, false>,
-        rt_render_paths_kernel<false, true, false>,  rt_render_paths_kernel<true, true, false>,
-        rt_render_paths_kernel<false, false, true>,  rt_render_paths_kernel<true, false, true>,
-        rt_render_paths_kernel<false, true, true>,   rt_render_paths_kernel<true, true, true>};
-    return table[(stats ? 1 : 0) | (big ? 2 : 0) | (extra ? 4 : 0)];
+paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop) {
+#define RT_V4(C) \
+    rt_render_paths_kernel<false, false, false, C>, rt_render_paths_kernel<true, false, false, C>, \
+    rt_render_paths_kernel<false, true, false, C>,  rt_render_paths_kernel<true, true, false, C>,  \
+    rt_render_paths_kernel<false, false, true, C>,  rt_render_paths_kernel<true, false, true, C>,  \
+    rt_render_paths_kernel<false, true, true, C>,   rt_render_paths_kernel<true, true, true, C>
+    static const paths_fn table[16] = {RT_V4(false), RT_V4(true)};
+#undef RT_V4
+    return table[(stats ? 1 : 0) | (big ? 2 : 0) | (extra ? 4 : 0) | (coop ? 8 : 0)];
 }
 
 int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    for (int v = 0; v < 8; v++)
-        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
+    for (int v = 0; v < 16; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     c->mega_lds_set = (int)t.lds_bytes;
     return RT_OK;
@@ -1537,7 +1574,8 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         if (S == 1) return set_err(c, RT_ERR_NOMEM, "no device memory for the per-path radiance buffer");
         S = (S + 1) / 2;
     }
-    const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.tri_soa != nullptr, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0);
+    const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.tri_soa != nullptr, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
+                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     size_t ev_used = 0;

@@ -38,6 +38,7 @@ namespace rtd {
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
 // light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
+// light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [64 g, 64 g + 64), behind the light records
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
     const float4* items;
@@ -45,6 +46,7 @@ struct Scene {
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
+    const float4* light_boxes;
     const float4* spheres;
     const float* tex;
     long long n_tex;
@@ -710,12 +712,25 @@ __device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int tri, f3 hitPo
     return f;
 }
 
+// reflectType5 (material.h:280-336) sums the pdf of EVERY importance-sampled triangle for the sampled direction
+// (:315-323), an O(numLights) loop of ray / triangle tests per hit.  A kernel whose waves are converged around the
+// shading call can ask shade_triangle to stop in front of that loop (DEFER), run it with all 64 lanes for one
+// waiting lane after the other (wave_light_pdf) and finish with finish_type5.
+#ifndef RT_LIGHTS_COOP_MIN
+#define RT_LIGHTS_COOP_MIN 32  // fewer lights: the lane's own loop is cheaper
+#endif
+struct LightQuery {
+    bool pending;
+    f3 hitPos, outgoing, clr;
+    float pdf_cos;
+};
+
 // Material::reflect, material.h:41-106.  Returns true when the path terminates.
 template <bool STATS>
 // The bounce's dimensions 8+8j .. 15+8j are Philox blocks bb and bb+1 (bb = 2 + 2j): A = dims k0..k3,
 // B = dims k4..k7, consumed in the reference's call order.
 __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, const Rng& rng,
-                                               uint32_t bb, Counters& cn) {
+                                               uint32_t bb, Counters& cn, LightQuery* lq = nullptr) {
     const HitFrame hf = hit_frame(sc, tri, hitPos);
     const f3 normal = hf.normal;
     int type = 127;  // out-of-range material id -> "the color of error"
@@ -843,6 +858,14 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             if (cos_theta < 0.0f) cos_theta = 0.0f;
             const float inv_pi = 1.0f / 3.14159f;
             const float pdf_cos = cos_theta * inv_pi;
+            if (lq && sc.n_lights >= RT_LIGHTS_COOP_MIN) {  // the caller runs the light loop with the whole wave
+                lq->pending = true;
+                lq->hitPos = hitPos;
+                lq->outgoing = outgoing;
+                lq->clr = clr;
+                lq->pdf_cos = pdf_cos;
+                return false;
+            }
             float pdf_light = 0.0f;
             for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323
                 const float4* L = sc.lights + 5 * (size_t)i;
@@ -876,6 +899,76 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.emission = mk(1.0f, 0.0f, 1.0f);
             return true;
     }
+}
+
+// The tail of reflectType5 behind the light loop (material.h:324-335).
+__device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, const LightQuery& q, float pdf_light) {
+    const float pdf = (sc.n_lights > 0) ? (0.5f * q.pdf_cos + 0.5f * pdf_light) : q.pdf_cos;
+    if (pdf <= 1e-12f) {
+        ray.thr = mk(0.f, 0.f, 0.f);
+        return;
+    }
+    ray.thr = ray.thr * q.clr * (q.pdf_cos / pdf);
+    ray.d = q.outgoing;
+    ray.o = ray.o + ray.d * 1e-5f;
+}
+
+// Can the ray o + t d, t >= 0, reach the box?  Errs on the side of yes (the boxes are padded at upload and the
+// comparison has slack), since a no skips triangle tests whose outcome must not change.
+__device__ __forceinline__ bool ray_may_reach_box(f3 o, f3 d, float4 mn, float4 mx) {
+    float tmin = 0.0f, tmax = 3e38f;
+    bool ok = true;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (dd[k] == 0.0f) {
+            ok = ok && oo[k] >= lo[k] && oo[k] <= hi[k];
+        } else {
+            const float inv = 1.0f / dd[k];
+            const float t1 = (lo[k] - oo[k]) * inv, t2 = (hi[k] - oo[k]) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2));
+            tmax = fminf(tmax, fmaxf(t1, t2));
+        }
+    }
+    return ok && tmin <= tmax * 1.00001f;
+}
+
+// The light loop of reflectType5 for every lane with a pending query, one after the other, 64 lights per step.
+// Call with the wave converged.  Same sum as the lane's own loop: terms are added in light order, and the terms
+// left out are the +0 of triangles the direction misses (x + 0 = x).  Groups of 64 lights whose bounds the ray
+// cannot reach are skipped for the same reason.
+template <bool STATS>
+__device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuery& q, Counters& cn) {
+    const int lane = threadIdx.x & 63;
+    const int n_groups = (sc.n_lights + 63) >> 6;
+    float result = 0.0f;
+    for (unsigned long long m = __ballot(q.pending); m; m &= m - 1) {
+        const int ow = __ffsll((long long)m) - 1;
+        const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
+        const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
+        float acc = 0.0f;
+        for (int gbase = 0; gbase < n_groups; gbase += 64) {
+            bool reach = false;
+            if (gbase + lane < n_groups)
+                reach = ray_may_reach_box(hp, og, sc.light_boxes[2 * (gbase + lane)], sc.light_boxes[2 * (gbase + lane) + 1]);
+            for (unsigned long long gm = __ballot(reach); gm; gm &= gm - 1) {
+                const int i = ((gbase + __ffsll((long long)gm) - 1) << 6) + lane;
+                float term = 0.0f;
+                if (i < sc.n_lights) {
+                    const float4* L = sc.lights + 5 * (size_t)i;
+                    const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+                    term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
+                                    l3.x) / (float)sc.n_lights;
+                }
+                for (unsigned long long h = __ballot(term != 0.0f); h; h &= h - 1) acc += lane_f(term, __ffsll((long long)h) - 1);
+            }
+        }
+        if (lane == ow) {
+            result = acc;
+            if (STATS) cn.lights += (uint32_t)sc.n_lights;
+        }
+    }
+    return result;
 }
 
 // Sphere::hitSphere, sphere.h:77-88

@@ -147,7 +147,7 @@ def random_scene(rt, seed):
     mats[4].image_offset[0] = 0; mats[4].image_width = 16; mats[4].image_height = 32
     mid = rng.integers(0, len(mats), n)
     t[:, 24] = mid + 0.001
-    lights = rng.random(n) < 0.03
+    lights = rng.random(n) < (0.03 if seed % 2 else 0.2)                   # up to ~300: the wave-cooperative light loop, several groups
     t[lights, 24] = 1 + 1000 + 0.001                                      # emissive + importance sampled
     depth = int(rng.choice([3, 6, 16]))
     sc = rt.Scene.from_records(t, mats, textures=tex, bvh_max_depth=depth, bvh_min_tris=int(rng.choice([1, 4, 9])))
