@@ -1332,8 +1332,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once
-    const int n_light_groups = (std::max(s->n_light_tris, 1) + 63) / 64;
-    const size_t light_box_off = (size_t)std::max(s->n_light_tris, 1) * 20;  // padded bounds per 64 lights behind the records
+    const int n_light_groups = (std::max(s->n_light_tris, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
+    const size_t light_box_off = (size_t)std::max(s->n_light_tris, 1) * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records
     std::vector<float> lights(light_box_off + (size_t)n_light_groups * 8, 0.f);
     for (int g = 0; g < n_light_groups; g++)
         for (int k = 0; k < 3; k++) {
@@ -1354,7 +1354,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         L[0] = p1.x; L[1] = p1.y; L[2] = p1.z; L[3] = e1.x; L[4] = e1.y; L[5] = e1.z;
         L[6] = e2.x; L[7] = e2.y; L[8] = e2.z; L[9] = nrm.x; L[10] = nrm.y; L[11] = nrm.z;
         L[12] = area; L[13] = p2.x; L[14] = p2.y; L[15] = p2.z; L[16] = p3.x; L[17] = p3.y; L[18] = p3.z; L[19] = 0.f;
-        float* B = &lights[light_box_off + (size_t)(i / 64) * 8];
+        float* B = &lights[light_box_off + (size_t)(i / RT_LIGHT_GROUP) * 8];
         for (int k = 0; k < 3; k++) {
             B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
             B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));

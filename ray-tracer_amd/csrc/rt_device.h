@@ -38,7 +38,7 @@ namespace rtd {
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
 // light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
-// light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [64 g, 64 g + 64), behind the light records
+// light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [16 g, 16 g + 16), behind the light records
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
     const float4* items;
@@ -915,46 +915,63 @@ __device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, co
 
 // Can the ray o + t d, t >= 0, reach the box?  Errs on the side of yes (the boxes are padded at upload and the
 // comparison has slack), since a no skips triangle tests whose outcome must not change.
-__device__ __forceinline__ bool ray_may_reach_box(f3 o, f3 d, float4 mn, float4 mx) {
-    float tmin = 0.0f, tmax = 3e38f;
-    bool ok = true;
-    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (dd[k] == 0.0f) {
-            ok = ok && oo[k] >= lo[k] && oo[k] <= hi[k];
-        } else {
-            const float inv = 1.0f / dd[k];
-            const float t1 = (lo[k] - oo[k]) * inv, t2 = (hi[k] - oo[k]) * inv;
-            tmin = fmaxf(tmin, fminf(t1, t2));
-            tmax = fminf(tmax, fmaxf(t1, t2));
-        }
+struct BoxRay {
+    f3 o, inv;
+    __device__ __forceinline__ void set(f3 origin, f3 d) {
+        o = origin;  // an axis the ray does not move along: a huge finite 1/d puts the slab's interval at -+1e26 and beyond
+        inv = mk(d.x == 0.0f ? 1e30f : 1.0f / d.x, d.y == 0.0f ? 1e30f : 1.0f / d.y, d.z == 0.0f ? 1e30f : 1.0f / d.z);
     }
-    return ok && tmin <= tmax * 1.00001f;
-}
+    __device__ __forceinline__ bool may_reach(float4 mn, float4 mx) const {
+        const float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x;
+        const float ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y;
+        const float az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
+        const float tmin = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+        const float tmax = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+        return tmin <= tmax * 1.00001f;
+    }
+};
 
-// The light loop of reflectType5 for every lane with a pending query, one after the other, 64 lights per step.
-// Call with the wave converged.  Same sum as the lane's own loop: terms are added in light order, and the terms
-// left out are the +0 of triangles the direction misses (x + 0 = x).  Groups of 64 lights whose bounds the ray
-// cannot reach are skipped for the same reason.
+// The light loop of reflectType5 for every lane with a pending query.  Call with the wave converged.  Same sum as
+// the lane's own loop: terms are added in light order, and the terms left out are the +0 of triangles the
+// direction misses (x + 0 = x).  Per pass over RT_LIGHT_CHUNK lights: every waiting lane marks the groups of
+// RT_LIGHT_GROUP lights whose bounds its ray can reach (all lanes at once, bounds through the scalar cache), then
+// lane after lane the wave tests the marked groups' triangles, four groups per step.
+#define RT_LIGHT_GROUP 16
+#define RT_LIGHT_CHUNK (64 * RT_LIGHT_GROUP)
 template <bool STATS>
 __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuery& q, Counters& cn) {
     const int lane = threadIdx.x & 63;
-    const int n_groups = (sc.n_lights + 63) >> 6;
+    const int slot = lane / RT_LIGHT_GROUP, sub = lane % RT_LIGHT_GROUP;
     float result = 0.0f;
-    for (unsigned long long m = __ballot(q.pending); m; m &= m - 1) {
-        const int ow = __ffsll((long long)m) - 1;
-        const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
-        const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
-        float acc = 0.0f;
-        for (int gbase = 0; gbase < n_groups; gbase += 64) {
-            bool reach = false;
-            if (gbase + lane < n_groups)
-                reach = ray_may_reach_box(hp, og, sc.light_boxes[2 * (gbase + lane)], sc.light_boxes[2 * (gbase + lane) + 1]);
-            for (unsigned long long gm = __ballot(reach); gm; gm &= gm - 1) {
-                const int i = ((gbase + __ffsll((long long)gm) - 1) << 6) + lane;
+    BoxRay br;
+    br.set(q.hitPos, q.outgoing);
+    for (int base = 0; base < sc.n_lights; base += RT_LIGHT_CHUNK) {
+        const int n_groups = min(64, (sc.n_lights - base + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP);
+        const float4* B = sc.light_boxes + 2 * (base / RT_LIGHT_GROUP);
+        unsigned long long mine = 0;
+        if (q.pending)
+            for (int g = 0; g < n_groups; g++)
+                if (br.may_reach(B[2 * g], B[2 * g + 1])) mine |= 1ull << g;
+        for (unsigned long long m = __ballot(mine != 0); m; m &= m - 1) {
+            const int ow = __ffsll((long long)m) - 1;
+            const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
+            const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
+            unsigned long long gm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), ow) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)mine, ow);
+            float acc = lane_f(result, ow);
+            while (gm) {
+                int g[64 / RT_LIGHT_GROUP];
+#pragma unroll
+                for (int k = 0; k < 64 / RT_LIGHT_GROUP; k++) {
+                    g[k] = gm ? __ffsll((long long)gm) - 1 : -1;
+                    gm &= gm - 1;
+                }
+                int gs = g[0];
+#pragma unroll
+                for (int k = 1; k < 64 / RT_LIGHT_GROUP; k++) gs = slot == k ? g[k] : gs;
+                const int i = base + gs * RT_LIGHT_GROUP + sub;
                 float term = 0.0f;
-                if (i < sc.n_lights) {
+                if (gs >= 0 && i < sc.n_lights) {
                     const float4* L = sc.lights + 5 * (size_t)i;
                     const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
                     term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
@@ -962,12 +979,10 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
                 }
                 for (unsigned long long h = __ballot(term != 0.0f); h; h &= h - 1) acc += lane_f(term, __ffsll((long long)h) - 1);
             }
-        }
-        if (lane == ow) {
-            result = acc;
-            if (STATS) cn.lights += (uint32_t)sc.n_lights;
+            if (lane == ow) result = acc;
         }
     }
+    if (STATS && q.pending) cn.lights += (uint32_t)sc.n_lights;
     return result;
 }
 
