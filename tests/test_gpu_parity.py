@@ -126,11 +126,11 @@ def test_sah_fast_mode_agrees_with_oracle_and_reference_tree(ob, rt, gpu, name):
     assert mean_rel < 0.02                                    # (scene.txt: identical; with lights: other picks, same mean)
 
 
-def random_scene(rt, seed):
+def random_scene(rt, seed, n=None, light_frac=None):
     """A random triangle soup with every material type, a texture, importance-sampled lights, clustered so that the
     BVH gets leaves of all sizes (incl. empty ones and, with a shallow tree, leaves big enough for the whole-wave test)."""
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(40, 1500))
+    n = int(rng.integers(40, 1500)) if n is None else n
     c = rng.normal(0, 1.5, (n, 1, 3)) + np.array([0, 0, -6.0])
     v = c + rng.normal(0, rng.choice([0.05, 0.3, 1.0]), (n, 3, 3))
     t = np.zeros((n, 25), np.float32)
@@ -147,7 +147,7 @@ def random_scene(rt, seed):
     mats[4].image_offset[0] = 0; mats[4].image_width = 16; mats[4].image_height = 32
     mid = rng.integers(0, len(mats), n)
     t[:, 24] = mid + 0.001
-    lights = rng.random(n) < (0.03 if seed % 2 else 0.2)                   # up to ~300: the wave-cooperative light loop, several groups
+    lights = rng.random(n) < ((0.03 if seed % 2 else 0.2) if light_frac is None else light_frac)                 # up to ~300: the wave-cooperative light loop, several groups
     t[lights, 24] = 1 + 1000 + 0.001                                      # emissive + importance sampled
     depth = int(rng.choice([3, 6, 16]))
     sc = rt.Scene.from_records(t, mats, textures=tex, bvh_max_depth=depth, bvh_min_tris=int(rng.choice([1, 4, 9])))
@@ -176,6 +176,24 @@ def test_random_scenes_all_schedules_match_oracle(ob, rt, gpu, seed):
     ov, _ = ob.render(sc, q, n_threads=8)
     gpu.reset(); gpu.render(q)
     assert np.array_equal(gpu.readback(), ov), seed
+
+
+@pytest.mark.parametrize("n,frac", [(2300, 0.5), (4000, 0.6)])
+def test_light_loop_over_several_chunks(ob, rt, gpu, n, frac):
+    """More than 1024 importance-sampled lights: the fused kernel's light loop (rt_device.h, wave_light_pdf) takes
+    several passes, the last one ragged; ids of the lights a ray crosses are far apart.  Bit-identical to the oracle's
+    plain loop over every light, and the same count of light tests."""
+    sc, rng = random_scene(rt, 77 + n, n=n, light_frac=frac)
+    assert len(sc.lights()) > 1024
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=4, width=96, height=80, max_bounces=5, flags=rt.F_BVH | rt.F_STATS)
+    p.seed = 5
+    o, ost = ob.render(sc, p, n_threads=8)
+    for mode in ("megakernel", "lockstep"):
+        q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
+        gpu.reset(); st = gpu.render(q)
+        assert np.array_equal(gpu.readback(), o), mode
+        assert st.light_tests == ost.light_tests and st.light_tests > 0, mode
 
 
 def image_metrics(a, b):
