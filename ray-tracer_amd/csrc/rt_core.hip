@@ -1380,13 +1380,84 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     const int root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    // ---- big leaves (rt_device.h, trav_big_leaf): blocks of 64 triangles, 64 x q0, 64 x q1, 64 x q2, a big leaf's triangles
+    // sorted along a Morton curve through their centroids; q2.z = triangles in the leaf, q2.w = the triangle's place in the
+    // reference's array; behind the blocks the padded bounds of every 16 positions
     std::vector<float> soa;
-    if (any_big) {  // blocks of 64 triangles: 64 x q0, 64 x q1, 64 x q2
-        soa.assign(((size_t)ntri + 63) / 64 * 192 * 4, 0.f);
-        for (int i = 0; i < ntri; i++) {
-            const float* h = &items[((size_t)n_inner + i) * 16];
+    size_t tri_box_off = 0;
+    if (any_big) {
+        std::vector<int> at((size_t)ntri);  // position -> triangle
+        std::vector<int> leaf_cnt((size_t)ntri, 0);
+        for (int i = 0; i < ntri; i++) at[(size_t)i] = i;
+        auto centroid = [&](int tri, int k) {
+            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+            return (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+        };
+        std::vector<std::pair<uint32_t, int>> keyed;
+        for (int i = 0; i < nn; i++) {
+            const rt_bvh_node& n = s->nodes[i];
+            if (n.child_a != -1) continue;
+            const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+            if (cnt < big_leaf) continue;
+            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+            for (int k = 0; k < cnt; k++)
+                for (int a = 0; a < 3; a++) {
+                    const float cc = centroid(first + k, a);
+                    lo[a] = std::min(lo[a], cc);
+                    hi[a] = std::max(hi[a], cc);
+                }
+            keyed.resize((size_t)cnt);
+            for (int k = 0; k < cnt; k++) {
+                uint32_t code = 0;
+                for (int a = 0; a < 3; a++) {
+                    const float ext = hi[a] - lo[a];
+                    uint32_t q = ext > 0.f ? (uint32_t)std::min(1023.f, (centroid(first + k, a) - lo[a]) / ext * 1024.f) : 0u;
+                    q = (q | (q << 16)) & 0x030000FFu;  // spread 10 bits to every third
+                    q = (q | (q << 8)) & 0x0300F00Fu;
+                    q = (q | (q << 4)) & 0x030C30C3u;
+                    q = (q | (q << 2)) & 0x09249249u;
+                    code |= q << a;
+                }
+                keyed[(size_t)k] = {code, first + k};
+            }
+            std::sort(keyed.begin(), keyed.end());
+            for (int k = 0; k < cnt; k++) {
+                at[(size_t)first + k] = keyed[(size_t)k].second;
+                leaf_cnt[(size_t)first + k] = cnt;
+            }
+        }
+        const size_t n_blocks = ((size_t)ntri + 63) / 64, n_boxes = ((size_t)ntri + 15) / 16;
+        tri_box_off = n_blocks * 192 * 4;
+        soa.assign(tri_box_off + n_boxes * 8, 0.f);
+        for (size_t g = 0; g < n_boxes; g++)
+            for (int k = 0; k < 3; k++) {
+                soa[tri_box_off + g * 8 + k] = 3e38f;
+                soa[tri_box_off + g * 8 + 4 + k] = -3e38f;
+            }
+        for (int p = 0; p < ntri; p++) {
+            const int tri = at[(size_t)p];
+            const float* h = &items[((size_t)n_inner + tri) * 16];
+            float q[12];
+            memcpy(q, h, sizeof(q));
+            q[10] = i2f(leaf_cnt[(size_t)p]);
+            q[11] = i2f(tri);
             for (int k = 0; k < 3; k++)
-                memcpy(&soa[(((size_t)i >> 6) * 192 + (size_t)k * 64 + (i & 63)) * 4], h + 4 * k, 16);
+                memcpy(&soa[(((size_t)p >> 6) * 192 + (size_t)k * 64 + (p & 63)) * 4], q + 4 * k, 16);
+            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+            float* B = &soa[tri_box_off + ((size_t)p >> 4) * 8];
+            for (int k = 0; k < 3; k++) {
+                B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
+                B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
+            }
+        }
+        for (size_t g = 0; g < n_boxes; g++) {  // pad: the culling test must never say no wrongly
+            float* B = &soa[tri_box_off + g * 8];
+            float scale = 1.f;
+            for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(B[k]), std::fabs(B[4 + k])));
+            for (int k = 0; k < 3; k++) {
+                B[k] -= 1e-4f * scale;
+                B[4 + k] += 1e-4f * scale;
+            }
         }
     }
 
@@ -1403,6 +1474,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
     sc.tri_soa = (const float4*)c->d_soa;
+    sc.tri_boxes = c->d_soa ? sc.tri_soa + tri_box_off / 4 : nullptr;
     sc.n_inner = n_inner;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;

@@ -43,6 +43,7 @@ namespace rtd {
 struct Scene {
     const float4* items;
     const float4* tri_soa;   // triangles once more, in blocks of 64: [q0 x 64][q1 x 64][q2 x 64]; null without big leaves
+    const float4* tri_boxes; // padded bounds (min, 0) (max, 0) of the triangles at positions [16 g, 16 g + 16) of tri_soa
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
@@ -538,48 +539,90 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
     visit_triangle<STATS>(sc, t, stk, cn, item, w[0], w[1], w[2]);
 }
 
-// A whole BIG leaf for every lane of `owners` (all of them stand at its first triangle, entry `first_item`):
-// per step the 64 lanes load 64 consecutive triangles of the leaf (coalesced, from tri_soa) and test them
-// against one owner's ray after the other, the ray travelling through v_readlane.  Same result as the walk of
-// main.cu:249-264: a later triangle replaces the hit only if strictly closer, so the winner is the closest
-// hit and, among equals, the first in array order -- candidates are taken in lane (= array) order with the
-// same strict comparison.
+// Can the ray o + t d, t >= 0, reach the box?  Errs on the side of yes (the boxes are padded at upload and the
+// comparison has slack), since a no skips triangle tests whose outcome must not change.
+struct BoxRay {
+    f3 o, inv;
+    __device__ __forceinline__ void set(f3 origin, f3 d) {
+        o = origin;  // an axis the ray does not move along: a huge finite 1/d puts the slab's interval at -+1e26 and beyond
+        inv = mk(d.x == 0.0f ? 1e30f : 1.0f / d.x, d.y == 0.0f ? 1e30f : 1.0f / d.y, d.z == 0.0f ? 1e30f : 1.0f / d.z);
+    }
+    __device__ __forceinline__ bool may_reach(float4 mn, float4 mx) const {
+        const float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x;
+        const float ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y;
+        const float az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
+        const float tmin = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+        const float tmax = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+        return tmin <= tmax * 1.00001f;
+    }
+};
+
+// A whole BIG leaf for every lane of `owners` (all of them stand at its first triangle, entry `first_item`), with
+// the whole wave and one owner's ray after the other, the ray travelling through v_readlane.  tri_soa holds a big
+// leaf's triangles sorted along a space-filling curve, with the leaf's triangle count and each triangle's place in
+// the reference's array; tri_boxes bounds every 16 of them.  Per owner: the lanes test the leaf's boxes, then four
+// reachable groups of 16 triangles per step.  Same result as the walk of main.cu:249-264: there a later triangle
+// replaces the hit only if strictly closer, so the winner is the closest hit below the distance the ray arrived
+// with and, among equals, the first in array order -- which does not depend on the order of the tests; a triangle
+// in a group the ray cannot reach is a triangle it misses.
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <bool STATS>
 __device__ __forceinline__ void trav_big_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int first_item,
                                               unsigned long long owners) {
     const int lane = threadIdx.x & 63;
-    for (int base = first_item - sc.n_inner;; base += 64) {  // triangle index of lane 0
-        const int tri = base + lane;
-        const bool in_array = tri < sc.n_tris;
-        const int tc = in_array ? tri : sc.n_tris - 1;
-        const float4* w = sc.tri_soa + (size_t)(tc >> 6) * 192 + (tc & 63);
-        const float4 q0 = w[0], q1 = w[64], q2 = w[128];
-        const unsigned long long mLast = __ballot(in_array && (__float_as_int(q2.y) & 1));
-        const int n_valid = mLast ? __ffsll((long long)mLast) : 64;  // triangles of the leaf in this step
-        const f3 v0 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
-        for (unsigned long long m = owners; m; m &= m - 1) {
-            const int ow = __ffsll((long long)m) - 1;
-            const f3 o = mk(lane_f(t.oxy.x, ow), lane_f(t.oxy.y, ow), lane_f(t.oz, ow));
-            const f3 d = mk(lane_f(t.d.x, ow), lane_f(t.d.y, ow), lane_f(t.d.z, ow));
-            float best = lane_f(t.minD2, ow);
-            float ht = 0.0f, nd = 0.0f;
-            bool hit = lane < n_valid && ray_triangle_t(o, d, v0, e1, e2, ht);
-            if (hit) nd = len2((o + d * ht) - o);
-            int winner = -1;
-            for (unsigned long long mc = __ballot(hit && nd < best); mc; mc &= mc - 1) {
-                const int l = __ffsll((long long)mc) - 1;
-                const float ndl = lane_f(nd, l);
-                if (ndl < best) { best = ndl; winner = l; }
+    const int slot = lane >> 4, sub = lane & 15;
+    const int pos0 = first_item - sc.n_inner;
+    const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(sc.tri_soa[(size_t)(pos0 >> 6) * 192 + 128 + (pos0 & 63)].z));
+    const int g0 = pos0 >> 4, ng = ((pos0 + cnt - 1) >> 4) - g0 + 1;
+    for (unsigned long long m = owners; m; m &= m - 1) {
+        const int ow = __ffsll((long long)m) - 1;
+        const f3 o = mk(lane_f(t.oxy.x, ow), lane_f(t.oxy.y, ow), lane_f(t.oz, ow));
+        const f3 d = mk(lane_f(t.d.x, ow), lane_f(t.d.y, ow), lane_f(t.d.z, ow));
+        BoxRay br;
+        br.o = o;
+        br.inv = mk(d.x == 0.0f ? 1e30f : lane_f(t.ixy.x, ow), d.y == 0.0f ? 1e30f : lane_f(t.ixy.y, ow), d.z == 0.0f ? 1e30f : lane_f(t.iz, ow));
+        float best = lane_f(t.minD2, ow), bestT = 0.0f;
+        int bestTri = -1;
+        for (int gb = 0; gb < ng; gb += 64) {
+            bool reach = false;
+            if (gb + lane < ng) {
+                const float4* B = sc.tri_boxes + 2 * (size_t)(g0 + gb + lane);
+                reach = br.may_reach(B[0], B[1]);
             }
-            if (winner >= 0) {
-                const float htw = lane_f(ht, winner);
-                if (lane == ow) { t.minD2 = best; t.set_hit(htw, mk(0.f, 0.f, 0.f)); t.hitTri = base + winner; }
+            unsigned long long gm = __ballot(reach);
+            while (gm) {
+                int g[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    g[k] = gm ? __ffsll((long long)gm) - 1 : -1;
+                    gm &= gm - 1;
+                }
+                const int gs = slot == 3 ? g[3] : slot == 2 ? g[2] : slot == 1 ? g[1] : g[0];
+                const int pos = (g0 + gb + gs) * 16 + sub;
+                const bool valid = gs >= 0 && pos >= pos0 && pos < pos0 + cnt;
+                const int pc = valid ? pos : pos0;
+                const float4* w = sc.tri_soa + (size_t)(pc >> 6) * 192 + (pc & 63);
+                const float4 q0 = w[0], q1 = w[64], q2 = w[128];
+                float ht = 0.0f, nd = 0.0f;
+                const bool hit = valid && ray_triangle_t(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht);
+                if (hit) nd = len2((o + d * ht) - o);
+                for (unsigned long long mc = __ballot(hit && nd <= best); mc; mc &= mc - 1) {
+                    const int l = __ffsll((long long)mc) - 1;
+                    const float ndl = lane_f(nd, l);
+                    const int tri = __builtin_amdgcn_readlane(__float_as_int(q2.w), l);
+                    if (ndl < best || (ndl == best && tri < bestTri)) {  // (bestTri -1: the hit the ray arrived with stays)
+                        best = ndl;
+                        bestTri = tri;
+                        bestT = lane_f(ht, l);
+                    }
+                }
             }
-            if (STATS && lane == ow) { cn.tri += n_valid; cn.leaf += (base == first_item - sc.n_inner); }
         }
-        if (mLast) break;
+        if (lane == ow) {
+            if (bestTri >= 0) { t.minD2 = best; t.set_hit(bestT, mk(0.f, 0.f, 0.f)); t.hitTri = bestTri; }
+            if (STATS) { cn.tri += cnt; cn.leaf++; }
+        }
     }
     if ((owners >> lane) & 1) trav_pop(t, stk);
 }
@@ -912,24 +955,6 @@ __device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, co
     ray.d = q.outgoing;
     ray.o = ray.o + ray.d * 1e-5f;
 }
-
-// Can the ray o + t d, t >= 0, reach the box?  Errs on the side of yes (the boxes are padded at upload and the
-// comparison has slack), since a no skips triangle tests whose outcome must not change.
-struct BoxRay {
-    f3 o, inv;
-    __device__ __forceinline__ void set(f3 origin, f3 d) {
-        o = origin;  // an axis the ray does not move along: a huge finite 1/d puts the slab's interval at -+1e26 and beyond
-        inv = mk(d.x == 0.0f ? 1e30f : 1.0f / d.x, d.y == 0.0f ? 1e30f : 1.0f / d.y, d.z == 0.0f ? 1e30f : 1.0f / d.z);
-    }
-    __device__ __forceinline__ bool may_reach(float4 mn, float4 mx) const {
-        const float ax = (mn.x - o.x) * inv.x, bx = (mx.x - o.x) * inv.x;
-        const float ay = (mn.y - o.y) * inv.y, by = (mx.y - o.y) * inv.y;
-        const float az = (mn.z - o.z) * inv.z, bz = (mx.z - o.z) * inv.z;
-        const float tmin = fmaxf(fmaxf(0.0f, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
-        const float tmax = fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz)));
-        return tmin <= tmax * 1.00001f;
-    }
-};
 
 // The light loop of reflectType5 for every lane with a pending query.  Call with the wave converged.  Same sum as
 // the lane's own loop: terms are added in light order, and the terms left out are the +0 of triangles the
