@@ -214,7 +214,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_TRI_MIN 16  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
 #ifndef RT_BIG_LEAF
-#define RT_BIG_LEAF 48
+#define RT_BIG_LEAF 16  // leaves with at least this many triangles get a sub-tree (rt_device.h) ...
+#endif
+#ifndef RT_SUB_LEAF
+#define RT_SUB_LEAF 4   // ... with at most this many triangles per sub-leaf
 #endif
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_LANE_NEW (-2)
 #define RT_LANE_IDLE (-3)
 
-// BIG: the scene has big leaves (Scene::tri_soa), tested by the whole wave.  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
+// BIG: the scene has leaf sub-trees (rt_device.h).  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
 // (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
 template <bool STATS, bool BIG, bool EXTRA, bool COOP>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
@@ -440,34 +443,24 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         const bool at_inner = trav_at_inner(sc, t);
         const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
         const unsigned long long mLeaf = __ballot(at_leaf);
-        unsigned long long mBig = BIG ? __ballot(t.cur >= RT_ENTRY_BIG) : 0ull;
-        if (mBig) {  // big leaves at once, with the whole wave, whoever else waits
-            do {
-                const int lcur = __builtin_amdgcn_readlane(t.cur, __ffsll((long long)mBig) - 1);
-                const unsigned long long owners = __ballot(t.cur == lcur);  // lanes at the same leaf share its loads
-                RT_PROF_COUNT(cn, 0, 1);
-                if (t.cur == lcur) RT_PROF_LANE(cn, 1);
-                trav_big_leaf<STATS>(sc, t, stk, cn, lcur & ~RT_ENTRY_BIG, owners);
-                mBig &= ~owners;
-            } while (mBig);
-        } else if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
+        if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_leaf<STATS>(sc, t, stk, cn);
+                trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
             }
         } else {
             if (at_inner) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_inner<STATS>(sc, t, stk, cn, n_cached);
+                trav_step_inner<STATS, BIG>(sc, t, stk, cn, n_cached);
             }
         }
 #else
         if (t.cur >= 0) {
             RT_PROF_COUNT(cn, 0, 1);
             RT_PROF_LANE(cn, 1);
-            trav_step<STATS>(sc, t, stk, cn, n_cached);
+            trav_step<STATS, BIG>(sc, t, stk, cn, n_cached);
         }
 #endif
         RT_PROF_COUNT(cn, 2, RT_PROF_CLOCK() - pt0);
@@ -780,7 +773,7 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
             }
         }
         if (!__any(has)) break;  // nothing in flight: the queue is exhausted as well
-        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS>(sc, t, stk, cn, n_cached);
+        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS, true>(sc, t, stk, cn, n_cached);
         if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
             int tri = t.hitTri;
             f3 hp = tri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
@@ -816,7 +809,7 @@ __global__ void rt_hitinfo_kernel(Scene sc, const float* __restrict__ rays, cons
     const float4 h = hits[i];
     const int tri = __float_as_int(h.w);
     const f3 o = ld3(rays + i * 6), pos = mk(h.x, h.y, h.z);
-    if (prim) prim[i] = tri;
+    if (prim) prim[i] = tri >= 0 ? tri_id(sc, tri) : tri;  // the reference's triangle id
     if (t) t[i] = tri >= 0 ? sqrtf(len2(pos - o)) : -1.0f;  // sqrt of the closest-hit metric, main.cu:257
     if (hit_pos) { hit_pos[i * 3] = tri >= 0 ? pos.x : 0.f; hit_pos[i * 3 + 1] = tri >= 0 ? pos.y : 0.f; hit_pos[i * 3 + 2] = tri >= 0 ? pos.z : 0.f; }
     if (normal3) {
@@ -877,7 +870,7 @@ __global__ void rt_shade_kernel(Scene sc, const float* __restrict__ in, size_t n
     Counters cn;
     cn.clear();
     bool term = true;
-    if (tri >= 0 && tri < sc.n_tris) term = shade_triangle<false>(sc, ray, hitPos, tri, rng, RT_RNG_DIM_BOUNCE0 >> 2, cn);
+    if (tri >= 0 && tri < sc.n_tris) term = shade_triangle<false>(sc, ray, hitPos, sc.tri_place[tri], rng, RT_RNG_DIM_BOUNCE0 >> 2, cn);
     o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z;
     o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
     o[6] = ray.thr.x; o[7] = ray.thr.y; o[8] = ray.thr.z;
@@ -1012,7 +1005,7 @@ struct rt_context {
     // scene (device)
     bool has_scene = false;
     Scene sc{};
-    void* d_items = nullptr; void* d_cold = nullptr; void* d_soa = nullptr;
+    void* d_items = nullptr; void* d_cold = nullptr; void* d_place = nullptr;
     void* d_mats = nullptr; void* d_lights = nullptr; void* d_spheres = nullptr; void* d_tex = nullptr;
     int bvh_depth = 0;
 
@@ -1054,7 +1047,7 @@ int set_err(rt_context* c, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(rt_context* c) {
-    void** ptrs[] = {&c->d_items, &c->d_soa, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
+    void** ptrs[] = {&c->d_items, &c->d_place, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -1260,58 +1253,136 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (max_depth > RT_STACK_ENTRIES)
         return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
-    int big_leaf = RT_BIG_LEAF;  // leaves with at least this many triangles are tested by the whole wave
-    if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(1, atoi(e));  // experiments only
-    bool any_big = false;
+    // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles gets a tree of its own -- median splits
+    //      of the centroids along the widest axis, sub-leaves of at most sub_leaf triangles, padded boxes; the triangles
+    //      are reordered inside the leaf only
+    int big_leaf = RT_BIG_LEAF, sub_leaf = RT_SUB_LEAF;
+    if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(2, atoi(e));  // experiments only
+    if (const char* e = getenv("RT_SUB_LEAF")) sub_leaf = std::max(1, atoi(e));  // experiments only
+    struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
+    std::vector<SubNode> subs;
+    std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
+    std::vector<int> leaf_end((size_t)std::max(ntri, 1), 0), sub_root((size_t)std::max(nn, 1), -1);
+    std::vector<unsigned char> tflags((size_t)std::max(ntri, 1), 0);
+    std::vector<char> covered((size_t)std::max(ntri, 1), 0);
+    for (int i = 0; i < ntri; i++) at[(size_t)i] = i;
+    auto centroid = [&](int tri, int k) {
+        const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+        return (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+    };
+    int deepest = max_depth;  // of the whole structure: sizes the traversal stack
+    auto build_sub = [&](auto&& self, int lo, int hi, int d, float* box) -> int {  // d: depth of this node
+        float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
+        for (int k = 0; k < 3; k++) { box[k] = 3e38f; box[3 + k] = -3e38f; }
+        for (int p = lo; p < hi; p++) {
+            const float* t = tris + (size_t)at[(size_t)p] * RT_TRI_FLOATS;
+            for (int k = 0; k < 3; k++) {
+                box[k] = std::min(box[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
+                box[3 + k] = std::max(box[3 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
+                const float cc = centroid(at[(size_t)p], k);
+                cmn[k] = std::min(cmn[k], cc);
+                cmx[k] = std::max(cmx[k], cc);
+            }
+        }
+        float scale = 1.f;  // pad: a sub-tree box must never make the ray miss a triangle it hits
+        for (int k = 0; k < 6; k++) scale = std::max(scale, std::fabs(box[k]));
+        for (int k = 0; k < 3; k++) { box[k] -= 1e-4f * scale; box[3 + k] += 1e-4f * scale; }
+        deepest = std::max(deepest, d);
+        if (hi - lo <= sub_leaf || d >= RT_STACK_ENTRIES) {
+            for (int p = lo; p < hi; p++) tflags[(size_t)p] = (unsigned char)(4 | (p == hi - 1 ? 1 : 0));
+            return ~lo;
+        }
+        int axis = 0;
+        for (int k = 1; k < 3; k++)
+            if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+        const int mid = lo + (hi - lo) / 2;
+        std::nth_element(at.begin() + lo, at.begin() + mid, at.begin() + hi, [&](int a, int b) {
+            const float ca = centroid(a, axis), cb = centroid(b, axis);
+            return ca < cb || (ca == cb && a < b);
+        });
+        const int idx = (int)subs.size();
+        subs.push_back(SubNode());
+        float ba[6], bb[6];
+        const int ea = self(self, lo, mid, d + 1, ba), eb = self(self, mid, hi, d + 1, bb);
+        SubNode& nd = subs[(size_t)idx];
+        memcpy(nd.box[0], ba, sizeof(ba));
+        memcpy(nd.box[1], bb, sizeof(bb));
+        nd.e[0] = ea;
+        nd.e[1] = eb;
+        nd.cnt = 0;
+        return idx;
+    };
+    for (int i = 0; i < nn; i++) {
+        const rt_bvh_node& n = s->nodes[i];
+        if (n.child_a != -1) continue;
+        const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+        for (int k = 0; k < cnt; k++) {
+            // a triangle in two leaves would need two "last" flags: the reference builder never does that
+            if (covered[(size_t)first + k]) return set_err(c, RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
+            covered[(size_t)first + k] = 1;
+            tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
+            leaf_end[(size_t)first + k] = first + cnt;
+        }
+        if (cnt >= big_leaf && cnt > sub_leaf && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
+            float box[6];
+            const int root = build_sub(build_sub, first, first + cnt, depth[i], box);
+            subs[(size_t)root].cnt = cnt;
+            sub_root[(size_t)i] = root;
+        }
+    }
+    const int n_top = n_inner, n_sub = (int)subs.size();
+    n_inner = n_top + n_sub;
+    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     auto entry_of = [&](int node) -> int {
         const rt_bvh_node& n = s->nodes[node];
         if (n.child_a != -1) return inner_index[node];
         if (n.tri_len == 0) return RT_TRAV_EMPTY;
-        const int e = n_inner + n.tri_offs / RT_TRI_FLOATS;
-        if (n.tri_len / RT_TRI_FLOATS < big_leaf) return e;
-        any_big = true;
-        return e | RT_ENTRY_BIG;
+        if (sub_root[(size_t)node] >= 0) return n_top + sub_root[(size_t)node];
+        return n_inner + n.tri_offs / RT_TRI_FLOATS;
     };
     std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
     std::vector<float> cold((size_t)std::max(ntri, 1) * 16, 0.f);
-    for (int i = 0; i < ntri; i++) {
-        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
-        float* h = &items[((size_t)n_inner + i) * 16];
-        float* cd = &cold[(size_t)i * 16];
-        const int mat = static_cast<int>(t[24]);  // main.cu:353
+    std::vector<int> place((size_t)std::max(ntri, 1), 0);  // triangle -> place
+    for (int p = 0; p < ntri; p++) {
+        const int tri = at[(size_t)p];
+        place[(size_t)tri] = p;
+        const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+        float* h = &items[((size_t)n_inner + p) * 16];
         h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
         h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
         h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
-        h[9] = i2f(0); h[10] = i2f(mat); h[11] = 0.f;
-        for (int k = 0; k < 15; k++) cd[k] = t[9 + k];
-        cd[15] = i2f(mat);
+        h[9] = i2f((int)tflags[(size_t)p]); h[10] = i2f(leaf_end[(size_t)p]); h[11] = i2f(tri);
     }
-    std::vector<char> covered(std::max(ntri, 1), 0);
+    for (int i = 0; i < ntri; i++) {
+        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
+        float* cd = &cold[(size_t)i * 16];
+        for (int k = 0; k < 15; k++) cd[k] = t[9 + k];
+        cd[15] = i2f(static_cast<int>(t[24]));  // main.cu:353
+    }
     for (int i = 0; i < nn; i++) {
         const rt_bvh_node& n = s->nodes[i];
-        if (n.child_a == -1) {
-            const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-            for (int k = 0; k < cnt; k++) {
-                // a triangle in two leaves would need two "last" flags: the reference builder never does that
-                if (covered[first + k]) return set_err(c, RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
-                covered[first + k] = 1;
-                int flags = 0;
-                if (k == cnt - 1) flags |= 1;
-                if (k == 0) flags |= 2;
-                items[((size_t)n_inner + first + k) * 16 + 9] = i2f(flags);
-            }
-        } else {
-            float* w = &items[(size_t)inner_index[i] * 16];
-            const rt_bvh_node& A = s->nodes[n.child_a];
-            const rt_bvh_node& B = s->nodes[n.child_b];
-            w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_max[0]; w[3] = A.bbox_max[1];
-            w[4] = B.bbox_min[0]; w[5] = B.bbox_min[1]; w[6] = B.bbox_max[0]; w[7] = B.bbox_max[1];
-            w[8] = A.bbox_min[2]; w[9] = A.bbox_max[2]; w[10] = B.bbox_min[2]; w[11] = B.bbox_max[2];
-            w[12] = i2f(entry_of(n.child_a));
-            w[13] = i2f(entry_of(n.child_b));
-            w[14] = i2f(i);
-            w[15] = 0.f;
-        }
+        if (n.child_a == -1) continue;
+        float* w = &items[(size_t)inner_index[i] * 16];
+        const rt_bvh_node& A = s->nodes[n.child_a];
+        const rt_bvh_node& B = s->nodes[n.child_b];
+        w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_max[0]; w[3] = A.bbox_max[1];
+        w[4] = B.bbox_min[0]; w[5] = B.bbox_min[1]; w[6] = B.bbox_max[0]; w[7] = B.bbox_max[1];
+        w[8] = A.bbox_min[2]; w[9] = A.bbox_max[2]; w[10] = B.bbox_min[2]; w[11] = B.bbox_max[2];
+        w[12] = i2f(entry_of(n.child_a));
+        w[13] = i2f(entry_of(n.child_b));
+        w[14] = i2f(i);
+        w[15] = 0.f;
+    }
+    for (int j = 0; j < n_sub; j++) {
+        const SubNode& nd = subs[(size_t)j];
+        float* w = &items[((size_t)n_top + j) * 16];
+        const float *A = nd.box[0], *B = nd.box[1];
+        w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
+        w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
+        w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
+        for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? n_top + nd.e[k] : n_inner + ~nd.e[k]);
+        w[14] = i2f(nd.cnt);
+        w[15] = i2f(1);
     }
 
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
@@ -1380,90 +1451,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     const int root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
-    // ---- big leaves (rt_device.h, trav_big_leaf): blocks of 64 triangles, 64 x q0, 64 x q1, 64 x q2, a big leaf's triangles
-    // sorted along a Morton curve through their centroids; q2.z = triangles in the leaf, q2.w = the triangle's place in the
-    // reference's array; behind the blocks the padded bounds of every 16 positions
-    std::vector<float> soa;
-    size_t tri_box_off = 0;
-    if (any_big) {
-        std::vector<int> at((size_t)ntri);  // position -> triangle
-        std::vector<int> leaf_cnt((size_t)ntri, 0);
-        for (int i = 0; i < ntri; i++) at[(size_t)i] = i;
-        auto centroid = [&](int tri, int k) {
-            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
-            return (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
-        };
-        std::vector<std::pair<uint32_t, int>> keyed;
-        for (int i = 0; i < nn; i++) {
-            const rt_bvh_node& n = s->nodes[i];
-            if (n.child_a != -1) continue;
-            const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-            if (cnt < big_leaf) continue;
-            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-            for (int k = 0; k < cnt; k++)
-                for (int a = 0; a < 3; a++) {
-                    const float cc = centroid(first + k, a);
-                    lo[a] = std::min(lo[a], cc);
-                    hi[a] = std::max(hi[a], cc);
-                }
-            keyed.resize((size_t)cnt);
-            for (int k = 0; k < cnt; k++) {
-                uint32_t code = 0;
-                for (int a = 0; a < 3; a++) {
-                    const float ext = hi[a] - lo[a];
-                    uint32_t q = ext > 0.f ? (uint32_t)std::min(1023.f, (centroid(first + k, a) - lo[a]) / ext * 1024.f) : 0u;
-                    q = (q | (q << 16)) & 0x030000FFu;  // spread 10 bits to every third
-                    q = (q | (q << 8)) & 0x0300F00Fu;
-                    q = (q | (q << 4)) & 0x030C30C3u;
-                    q = (q | (q << 2)) & 0x09249249u;
-                    code |= q << a;
-                }
-                keyed[(size_t)k] = {code, first + k};
-            }
-            std::sort(keyed.begin(), keyed.end());
-            for (int k = 0; k < cnt; k++) {
-                at[(size_t)first + k] = keyed[(size_t)k].second;
-                leaf_cnt[(size_t)first + k] = cnt;
-            }
-        }
-        const size_t n_blocks = ((size_t)ntri + 63) / 64, n_boxes = ((size_t)ntri + 15) / 16;
-        tri_box_off = n_blocks * 192 * 4;
-        soa.assign(tri_box_off + n_boxes * 8, 0.f);
-        for (size_t g = 0; g < n_boxes; g++)
-            for (int k = 0; k < 3; k++) {
-                soa[tri_box_off + g * 8 + k] = 3e38f;
-                soa[tri_box_off + g * 8 + 4 + k] = -3e38f;
-            }
-        for (int p = 0; p < ntri; p++) {
-            const int tri = at[(size_t)p];
-            const float* h = &items[((size_t)n_inner + tri) * 16];
-            float q[12];
-            memcpy(q, h, sizeof(q));
-            q[10] = i2f(leaf_cnt[(size_t)p]);
-            q[11] = i2f(tri);
-            for (int k = 0; k < 3; k++)
-                memcpy(&soa[(((size_t)p >> 6) * 192 + (size_t)k * 64 + (p & 63)) * 4], q + 4 * k, 16);
-            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
-            float* B = &soa[tri_box_off + ((size_t)p >> 4) * 8];
-            for (int k = 0; k < 3; k++) {
-                B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
-                B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
-            }
-        }
-        for (size_t g = 0; g < n_boxes; g++) {  // pad: the culling test must never say no wrongly
-            float* B = &soa[tri_box_off + g * 8];
-            float scale = 1.f;
-            for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(B[k]), std::fabs(B[4 + k])));
-            for (int k = 0; k < 3; k++) {
-                B[k] -= 1e-4f * scale;
-                B[4 + k] += 1e-4f * scale;
-            }
-        }
-    }
-
     free_scene(c);
     int rc;
-    if (any_big && (rc = upload_buf(c, &c->d_soa, soa.data(), soa.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_place, place.data(), place.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_items, items.data(), items.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_cold, cold.data(), cold.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_mats, mats.data(), mats.size() * 4)) != RT_OK) return rc;
@@ -1473,9 +1463,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
 
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
-    sc.tri_soa = (const float4*)c->d_soa;
-    sc.tri_boxes = c->d_soa ? sc.tri_soa + tri_box_off / 4 : nullptr;
+    sc.tri_place = (const int*)c->d_place;
     sc.n_inner = n_inner;
+    sc.n_sub = n_sub;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
@@ -1493,7 +1483,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         sc.root_min[k] = nn > 0 ? s->nodes[0].bbox_min[k] : 0.f;
         sc.root_max[k] = nn > 0 ? s->nodes[0].bbox_max[k] : 0.f;
     }
-    c->bvh_depth = max_depth;
+    c->bvh_depth = deepest;
     c->has_scene = true;
     return RT_OK;
 }
@@ -1646,7 +1636,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         if (S == 1) return set_err(c, RT_ERR_NOMEM, "no device memory for the per-path radiance buffer");
         S = (S + 1) / 2;
     }
-    const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.tri_soa != nullptr, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
+    const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.n_sub > 0, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
                                             c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;

@@ -20,21 +20,34 @@ namespace rtd {
 //
 // ITEM STREAM (64 B = 4 x float4 per item): inner nodes and triangles live in ONE array with ONE index
 // space, so a traversal cursor is a single int and a step -- an inner-node visit or one triangle test
-// -- is a few 16-byte loads at 64 * cursor.  Items [0, n_inner) are the INNER nodes of the reference BVH in its BFS order,
-// items [n_inner, n_inner + n_tris) the triangles in the reference's (leaf-contiguous) order.
+// -- is a few 16-byte loads at 64 * cursor.  Items [0, n_top) are the INNER nodes of the reference BVH in its BFS order,
+// items [n_top, n_inner) the inner nodes of LEAF SUB-TREES (below), items [n_inner, n_inner + n_tris) the triangles
+// in the reference's (leaf-contiguous) order, except inside a leaf with a sub-tree.
 //   inner item: both child boxes + both child entries (one 64-B fetch per inner visit instead
 //               of the reference's two 40-B child fetches, main.cu:268-269)
 //     q0 = (A.min.x, A.min.y, A.max.x, A.max.y)      x/y pairs and z pairs: the slab differences and
 //     q1 = (B.min.x, B.min.y, B.max.x, B.max.y)      products run as packed two-float operations
 //     q2 = (A.min.z, A.max.z, B.min.z, B.max.z)
 //     q3 = (entryA, entryB, refNodeId, 0)            as int bits
+//          sub-tree node: (entryA, entryB, triangles of the leaf [root of the sub-tree] or 0, 1)
 //     entry = item index of the child (inner node, or FIRST triangle of a leaf child),
 //             RT_TRAV_EMPTY for a leaf without triangles
 //   triangle item: v0, e1 = v1 - v0, e2 = v2 - v0 (the single subtraction of main.cu:43-44 done
 //               at upload, bit-identical)
 //     q0 = (v0.x, v0.y, v0.z, e1.x)  q1 = (e1.y, e1.z, e2.x, e2.y)
-//     q2 = (e2.z, flags, matId, 0)   flags bit0 = last triangle of its leaf, bit1 = first
+//     q2 = (e2.z, flags, leafEnd, id)  flags bit0 = last triangle of its (sub-)leaf, bit1 = first of a reference
+//                                      leaf, bit2 = inside a sub-tree (its test is counted at the sub-tree's root);
+//                                      leafEnd = one past the last triangle of its reference leaf; id = the
+//                                      triangle's place in the reference's array (= its place here without sub-trees)
 //     q3 = unused
+// LEAF SUB-TREES.  The reference tests EVERY triangle of a leaf, in array order, and a later triangle replaces the
+// hit only if strictly closer (main.cu:249-264): the leaf's result is the closest hit below the distance the ray
+// arrived with and, among equals, the one first in the array -- which does not depend on the order of the tests, and
+// a triangle the ray misses contributes nothing.  A leaf with many triangles (the reference caps its tree at
+// depth 16: ~150 per leaf in a 10M-triangle scene) therefore gets a small tree of its own here: triangles
+// reordered inside the leaf, median splits, PADDED boxes and a pruning test with slack, so that a sub-tree node is
+// only skipped when no triangle in it can be a hit that counts.  Counters: the root of a sub-tree counts one
+// leaf visit and all the leaf's triangle tests, like the walk it replaces.
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
 // light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
@@ -42,8 +55,7 @@ namespace rtd {
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
     const float4* items;
-    const float4* tri_soa;   // triangles once more, in blocks of 64: [q0 x 64][q1 x 64][q2 x 64]; null without big leaves
-    const float4* tri_boxes; // padded bounds (min, 0) (max, 0) of the triangles at positions [16 g, 16 g + 16) of tri_soa
+    const int* tri_place;    // reference triangle id -> place in the item stream (callers' ids, test hooks)
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
@@ -51,7 +63,8 @@ struct Scene {
     const float4* spheres;
     const float* tex;
     long long n_tex;
-    int n_inner;
+    int n_inner;      // inner items: the reference's nodes, then the sub-tree nodes
+    int n_sub;        // sub-tree nodes among them (0: every triangle is at its reference place)
     int n_tris;
     int n_mats;
     int n_lights;
@@ -330,11 +343,6 @@ extern __shared__ float4 rt_lds[];  // dynamic LDS: [4 * n_cached node pieces][p
 
 #define RT_TRAV_DONE (-1)   // query finished
 #define RT_TRAV_EMPTY 0x3ffffff0  // a leaf without triangles (visited, nothing to test); sorts after every item index
-// Entry of a leaf with at least RT_BIG_LEAF triangles: item index | RT_ENTRY_BIG.  The path-parallel kernel tests
-// such a leaf with the whole wave (64 triangles per step, coalesced loads from tri_soa); everywhere else the bit
-// is masked off and the leaf is walked one triangle at a time.
-#define RT_ENTRY_BIG 0x40000000
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Per-lane traversal state of one closest-hit query.  Origin and 1/direction are kept as an (x, y) pair
@@ -348,7 +356,8 @@ struct Trav {
     __device__ __forceinline__ f3 inv() const { return mk(ixy.x, ixy.y, iz); }
     int cur;      // item to visit next (inner node or triangle), RT_TRAV_EMPTY, or RT_TRAV_DONE
     int sp;       // entries on this lane's LDS stack
-    int hitTri;   // triangle id (hitTriIndex / 25) or -1
+    int hitTri;   // place of the hit triangle in the item stream (Scene::tri_id gives hitTriIndex / 25), or -1
+    float slack;  // sub-tree pruning: bound on the rounding error of a squared distance from this origin
     float minD2;  // minDistSqr, main.cu:223
     float hitT;   // ray parameter of the closest hit: its position o + d * hitT is formed again when the query is
                   // over (same operands, same operations as main.cu:66 -> same bits) instead of being carried along
@@ -366,6 +375,10 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d,
     t.axis_parallel = !(fabsf(t.ixy.x) < INFINITY && fabsf(t.ixy.y) < INFINITY && fabsf(t.iz) < INFINITY);
     t.sp = 0;
     t.hitTri = -1;
+    {   // |fl(o + d t) - o|^2 is off by ~2 dist E, E = a few ulp of (|o| + dist); 2 dist E <= 4e-7 (|o|_1^2 + 3 dist^2)
+        const float osum = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+        t.slack = 1e-5f * osum * osum;
+    }
     t.minD2 = minD2_0;  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
     // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
@@ -443,10 +456,18 @@ __device__ __forceinline__ float aabb_distance_nb(f3 o, f3 inv, f3 mn, f3 mx) { 
     return inside ? 0.0f : r;
 }
 
-// Inner-node visit (main.cu:265-279) on the fetched item.
-template <bool STATS>
+// Inner-node visit (main.cu:265-279) on the fetched item.  SUB: the scene has leaf sub-trees.
+template <bool STATS, bool SUB>
 __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, float4 q0, float4 q1, float4 q2, float4 q3) {
-    if (STATS) cn.inner++;
+    const bool sub = SUB && __float_as_int(q3.w) != 0;
+    if (STATS) {
+        if (sub) {  // the root of a sub-tree stands for the visit of its leaf and the tests of all its triangles
+            cn.tri += (uint32_t)__float_as_int(q3.z);
+            cn.leaf += __float_as_int(q3.z) != 0;
+        } else {
+            cn.inner++;
+        }
+    }
 #if RT_INNER_PK
     const v2f oxy = t.oxy, ozz = {t.oz, t.oz}, ixy = t.ixy, izz = {t.iz, t.iz};
     float dA = aabb_distance_pk(oxy, ozz, ixy, izz, (v2f){q0.x, q0.y}, (v2f){q0.z, q0.w}, (v2f){q2.x, q2.y});
@@ -467,23 +488,38 @@ __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, flo
     const bool aNear = dA < dB;
     const int eNear = aNear ? eA : eB, eFar = aNear ? eB : eA;
     const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
-    if (dFar < t.minD2) { stk[t.sp * 64] = eFar; t.sp++; }
-    if (dNear < t.minD2) t.cur = eNear;
+    // the reference's rule for its own nodes; inside a sub-tree a child is skipped only if no triangle in its
+    // (padded) box can come out at or below minD2, whatever the rounding of either squared distance
+    const float lim = sub ? t.minD2 * 1.00002f + t.slack : t.minD2;
+    if (dFar < lim) { stk[t.sp * 64] = eFar; t.sp++; }
+    if (dNear < lim) t.cur = eNear;
     else trav_pop(t, stk);
 }
 
+// Equal squared distances inside one reference leaf: the reference keeps the triangle it met first, i.e. the one
+// with the smaller id (rare: the held hit's record is fetched again).
+__device__ __forceinline__ bool tie_replaces(const Scene& sc, int heldPlace, float4 q2, bool whole_array) {
+    if (heldPlace < 0) return false;
+    const float4 h2 = sc.items[4 * ((size_t)sc.n_inner + heldPlace) + 2];
+    return (whole_array || __float_as_int(h2.z) == __float_as_int(q2.z)) && __float_as_int(q2.w) < __float_as_int(h2.w);
+}
+
 // One triangle test of the current leaf (main.cu:249-264) on the fetched item.
-template <bool STATS>
+template <bool STATS, bool SUB>
 __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, int item, float4 q0, float4 q1,
                                                float4 q2) {
     const int flags = __float_as_int(q2.y);
-    if (STATS) { cn.tri++; cn.leaf += (flags >> 1) & 1; }
+    if (STATS) { cn.tri += !(flags & 4); cn.leaf += (flags >> 1) & 1; }
     float ht;
     const f3 o = t.o();
     if (ray_triangle_t(o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht)) {
         const f3 pos = o + t.d * ht;
         const float nd = len2(pos - o);
-        if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = item - sc.n_inner; }
+        if (nd < t.minD2 || (SUB && nd == t.minD2 && tie_replaces(sc, t.hitTri, q2, false))) {
+            t.minD2 = nd;
+            t.set_hit(ht, pos);
+            t.hitTri = item - sc.n_inner;
+        }
     }
     if (flags & 1) trav_pop(t, stk);
     else t.cur++;
@@ -492,7 +528,7 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
 // ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit or one
 // triangle test of the current leaf.  All lanes of the wave share the four item loads, whatever kind
 // of item each of them holds.
-template <bool STATS>
+template <bool STATS, bool SUB>
 __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached = 0) {
     if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
         if (STATS) cn.leaf++;
@@ -500,22 +536,21 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
         return;
     }
     float4 q0, q1, q2, q3;
-    const int item = t.cur & ~RT_ENTRY_BIG;
     if (t.cur < n_cached) {
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
-        const float4* w = sc.items + 4 * (size_t)item;
+        const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
-    if (t.cur < sc.n_inner) visit_inner<STATS>(t, stk, cn, q0, q1, q2, q3);
-    else visit_triangle<STATS>(sc, t, stk, cn, item, q0, q1, q2);
+    if (t.cur < sc.n_inner) visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
+    else visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
 }
 
 // The two kinds of step on their own, for schedulers that run them in separate wave-uniform phases
 // (rt_render_paths_kernel): an iteration then executes the code of one kind only.
 __device__ __forceinline__ bool trav_at_inner(const Scene& sc, const Trav& t) { return (unsigned)t.cur < (unsigned)sc.n_inner; }
 
-template <bool STATS>
+template <bool STATS, bool SUB>
 __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached) {  // trav_at_inner(t)
     float4 q0, q1, q2, q3;
     if (t.cur < n_cached) {
@@ -524,19 +559,42 @@ __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* s
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
-    visit_inner<STATS>(t, stk, cn, q0, q1, q2, q3);
+    visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
 }
 
-template <bool STATS>
+template <bool STATS, bool SUB>
 __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn) {  // a triangle or RT_TRAV_EMPTY
     if (t.cur == RT_TRAV_EMPTY) {
         if (STATS) cn.leaf++;
         trav_pop(t, stk);
         return;
     }
-    const int item = t.cur & ~RT_ENTRY_BIG;
-    const float4* w = sc.items + 4 * (size_t)item;
-    visit_triangle<STATS>(sc, t, stk, cn, item, w[0], w[1], w[2]);
+    const float4* w = sc.items + 4 * (size_t)t.cur;
+    visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, w[0], w[1], w[2]);
+}
+
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// ENABLE_BVH false, main.cu:285-301: every triangle, in array order there; here in item order with the tie rule
+template <bool STATS>
+__device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Counters& cn) {
+    for (int i = 0; i < sc.n_tris; i++) {
+        const float4* h = sc.items + 4 * ((size_t)sc.n_inner + i);
+        const float4 h0 = h[0], h1 = h[1], h2 = h[2];
+        if (STATS) cn.tri++;
+        float ht;
+        const f3 o = t.o();
+        if (ray_triangle_t(o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), ht)) {
+            const f3 pos = o + t.d * ht;
+            const float nd = len2(pos - o);
+            if (nd < t.minD2 || (sc.n_sub > 0 && nd == t.minD2 && tie_replaces(sc, t.hitTri, h2, true))) {
+                t.minD2 = nd;
+                t.set_hit(ht, pos);
+                t.hitTri = i;
+            }
+        }
+    }
+    t.cur = RT_TRAV_DONE;
 }
 
 // Can the ray o + t d, t >= 0, reach the box?  Errs on the side of yes (the boxes are padded at upload and the
@@ -556,94 +614,6 @@ struct BoxRay {
         return tmin <= tmax * 1.00001f;
     }
 };
-
-// A whole BIG leaf for every lane of `owners` (all of them stand at its first triangle, entry `first_item`), with
-// the whole wave and one owner's ray after the other, the ray travelling through v_readlane.  tri_soa holds a big
-// leaf's triangles sorted along a space-filling curve, with the leaf's triangle count and each triangle's place in
-// the reference's array; tri_boxes bounds every 16 of them.  Per owner: the lanes test the leaf's boxes, then four
-// reachable groups of 16 triangles per step.  Same result as the walk of main.cu:249-264: there a later triangle
-// replaces the hit only if strictly closer, so the winner is the closest hit below the distance the ray arrived
-// with and, among equals, the first in array order -- which does not depend on the order of the tests; a triangle
-// in a group the ray cannot reach is a triangle it misses.
-__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-
-template <bool STATS>
-__device__ __forceinline__ void trav_big_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int first_item,
-                                              unsigned long long owners) {
-    const int lane = threadIdx.x & 63;
-    const int slot = lane >> 4, sub = lane & 15;
-    const int pos0 = first_item - sc.n_inner;
-    const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(sc.tri_soa[(size_t)(pos0 >> 6) * 192 + 128 + (pos0 & 63)].z));
-    const int g0 = pos0 >> 4, ng = ((pos0 + cnt - 1) >> 4) - g0 + 1;
-    for (unsigned long long m = owners; m; m &= m - 1) {
-        const int ow = __ffsll((long long)m) - 1;
-        const f3 o = mk(lane_f(t.oxy.x, ow), lane_f(t.oxy.y, ow), lane_f(t.oz, ow));
-        const f3 d = mk(lane_f(t.d.x, ow), lane_f(t.d.y, ow), lane_f(t.d.z, ow));
-        BoxRay br;
-        br.o = o;
-        br.inv = mk(d.x == 0.0f ? 1e30f : lane_f(t.ixy.x, ow), d.y == 0.0f ? 1e30f : lane_f(t.ixy.y, ow), d.z == 0.0f ? 1e30f : lane_f(t.iz, ow));
-        float best = lane_f(t.minD2, ow), bestT = 0.0f;
-        int bestTri = -1;
-        for (int gb = 0; gb < ng; gb += 64) {
-            bool reach = false;
-            if (gb + lane < ng) {
-                const float4* B = sc.tri_boxes + 2 * (size_t)(g0 + gb + lane);
-                reach = br.may_reach(B[0], B[1]);
-            }
-            unsigned long long gm = __ballot(reach);
-            while (gm) {
-                int g[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    g[k] = gm ? __ffsll((long long)gm) - 1 : -1;
-                    gm &= gm - 1;
-                }
-                const int gs = slot == 3 ? g[3] : slot == 2 ? g[2] : slot == 1 ? g[1] : g[0];
-                const int pos = (g0 + gb + gs) * 16 + sub;
-                const bool valid = gs >= 0 && pos >= pos0 && pos < pos0 + cnt;
-                const int pc = valid ? pos : pos0;
-                const float4* w = sc.tri_soa + (size_t)(pc >> 6) * 192 + (pc & 63);
-                const float4 q0 = w[0], q1 = w[64], q2 = w[128];
-                float ht = 0.0f, nd = 0.0f;
-                const bool hit = valid && ray_triangle_t(o, d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht);
-                if (hit) nd = len2((o + d * ht) - o);
-                for (unsigned long long mc = __ballot(hit && nd <= best); mc; mc &= mc - 1) {
-                    const int l = __ffsll((long long)mc) - 1;
-                    const float ndl = lane_f(nd, l);
-                    const int tri = __builtin_amdgcn_readlane(__float_as_int(q2.w), l);
-                    if (ndl < best || (ndl == best && tri < bestTri)) {  // (bestTri -1: the hit the ray arrived with stays)
-                        best = ndl;
-                        bestTri = tri;
-                        bestT = lane_f(ht, l);
-                    }
-                }
-            }
-        }
-        if (lane == ow) {
-            if (bestTri >= 0) { t.minD2 = best; t.set_hit(bestT, mk(0.f, 0.f, 0.f)); t.hitTri = bestTri; }
-            if (STATS) { cn.tri += cnt; cn.leaf++; }
-        }
-    }
-    if ((owners >> lane) & 1) trav_pop(t, stk);
-}
-
-// ENABLE_BVH false, main.cu:285-301
-template <bool STATS>
-__device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Counters& cn) {
-    for (int i = 0; i < sc.n_tris; i++) {
-        const float4* h = sc.items + 4 * ((size_t)sc.n_inner + i);
-        const float4 h0 = h[0], h1 = h[1], h2 = h[2];
-        if (STATS) cn.tri++;
-        float ht;
-        const f3 o = t.o();
-        if (ray_triangle_t(o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), ht)) {
-            const f3 pos = o + t.d * ht;
-            const float nd = len2(pos - o);
-            if (nd < t.minD2) { t.minD2 = nd; t.set_hit(ht, pos); t.hitTri = i; }
-        }
-    }
-    t.cur = RT_TRAV_DONE;
-}
 
 // Analytic spheres after the triangles, main.cu:305-334.  Returns the sphere index or -1.
 __device__ __forceinline__ int trav_spheres(const Scene& sc, Trav& t, f3& sPos) {
@@ -675,7 +645,7 @@ __device__ __forceinline__ void trace_closest(const Scene& sc, f3 o, f3 d, bool 
     while (t.cur != RT_TRAV_DONE) {
         RT_PROF_COUNT(cn, 0, 1);
         RT_PROF_LANE(cn, 1);
-        trav_step<STATS>(sc, t, stk, cn, n_cached);
+        trav_step<STATS, true>(sc, t, stk, cn, n_cached);
     }
     hitTri = t.hitTri;
     minD2 = t.minD2;
@@ -739,10 +709,15 @@ struct HitFrame {
     int mat;
 };
 
-__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int tri, f3 hitPos) {  // material.h:44-62
-    const float4* t = sc.items + 4 * ((size_t)sc.n_inner + tri);
+// The reference's id (hitTriIndex / 25) of the triangle at a place of the item stream.
+__device__ __forceinline__ int tri_id(const Scene& sc, int place) {
+    return __float_as_int(sc.items[4 * ((size_t)sc.n_inner + place) + 2].w);
+}
+
+__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int place, f3 hitPos) {  // material.h:44-62
+    const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
     const float4 h0 = t[0], h1 = t[1], h2 = t[2];
-    const float4* c = sc.tri_cold + 4 * (size_t)tri;
+    const float4* c = sc.tri_cold + 4 * (size_t)__float_as_int(h2.w);  // (cold data stays in the reference's order)
     const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
     const f3 bary = barycentric(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), hitPos);
     const f3 n0 = mk(c0.x, c0.y, c0.z), n1 = mk(c0.w, c1.x, c1.y), n2 = mk(c1.z, c1.w, c2.x);
