@@ -214,11 +214,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_TRI_MIN 16  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
 #ifndef RT_BIG_LEAF
-#define RT_BIG_LEAF 16  // leaves with at least this many triangles get a sub-tree (rt_device.h) ...
+#define RT_BIG_LEAF 2           // leaves with at least this many triangles may get a sub-tree (rt_device.h) ...
 #endif
-#ifndef RT_SUB_LEAF
-#define RT_SUB_LEAF 4   // ... with at most this many triangles per sub-leaf
-#endif
+#define RT_SUB_COST_INNER 0.8f  // ... where the estimate says so: cost of a node visit in triangle tests,
+#define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
+#define RT_SUB_SWEEP_MAX 32     // full surface-area sweep up to this many triangles, median splits above
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
 #endif
@@ -1256,9 +1256,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles gets a tree of its own -- median splits
     //      of the centroids along the widest axis, sub-leaves of at most sub_leaf triangles, padded boxes; the triangles
     //      are reordered inside the leaf only
-    int big_leaf = RT_BIG_LEAF, sub_leaf = RT_SUB_LEAF;
-    if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(2, atoi(e));  // experiments only
-    if (const char* e = getenv("RT_SUB_LEAF")) sub_leaf = std::max(1, atoi(e));  // experiments only
+    int big_leaf = RT_BIG_LEAF;
+    float cost_inner = RT_SUB_COST_INNER;
+    if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(2, atoi(e));       // experiments only
+    if (const char* e = getenv("RT_SUB_COST_INNER")) cost_inner = (float)atof(e);      // experiments only
     struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
     std::vector<SubNode> subs;
     std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
@@ -1270,40 +1271,101 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
         return (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
     };
-    int deepest = max_depth;  // of the whole structure: sizes the traversal stack
-    auto build_sub = [&](auto&& self, int lo, int hi, int d, float* box) -> int {  // d: depth of this node
-        float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
-        for (int k = 0; k < 3; k++) { box[k] = 3e38f; box[3 + k] = -3e38f; }
-        for (int p = lo; p < hi; p++) {
-            const float* t = tris + (size_t)at[(size_t)p] * RT_TRI_FLOATS;
-            for (int k = 0; k < 3; k++) {
-                box[k] = std::min(box[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
-                box[3 + k] = std::max(box[3 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
-                const float cc = centroid(at[(size_t)p], k);
-                cmn[k] = std::min(cmn[k], cc);
-                cmx[k] = std::max(cmx[k], cc);
-            }
+    auto grow = [&](float* box, int tri) {
+        const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+        for (int k = 0; k < 3; k++) {
+            box[k] = std::min(box[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
+            box[3 + k] = std::max(box[3 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
         }
+    };
+    auto half_area = [](const float* b) {
+        const float x = b[3] - b[0], y = b[4] - b[1], z = b[5] - b[2];
+        return x * y + y * z + z * x;
+    };
+    const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+    std::vector<int> sorted;
+    std::vector<float> suffix;
+    int deepest = max_depth;  // of the whole structure: sizes the traversal stack
+    // One node of a sub-tree over the triangles at places [lo, hi), d = its depth in the whole structure.  Splits
+    // by the surface-area heuristic (sweep over the three axes for small sets, median of the widest axis above),
+    // and stops where the walk over the triangles is estimated cheaper than another node.  Returns the child entry.
+    auto build_sub = [&](auto&& self, int lo, int hi, int d, float* box, bool root) -> int {
+        const int n = hi - lo;
+        float tight[6];
+        memcpy(tight, kEmpty, sizeof(tight));
+        for (int p = lo; p < hi; p++) grow(tight, at[(size_t)p]);
+        memcpy(box, tight, sizeof(tight));
         float scale = 1.f;  // pad: a sub-tree box must never make the ray miss a triangle it hits
         for (int k = 0; k < 6; k++) scale = std::max(scale, std::fabs(box[k]));
         for (int k = 0; k < 3; k++) { box[k] -= 1e-4f * scale; box[3 + k] += 1e-4f * scale; }
         deepest = std::max(deepest, d);
-        if (hi - lo <= sub_leaf || d >= RT_STACK_ENTRIES) {
+        int mid = -1;
+        if (n >= 2 && d < RT_STACK_ENTRIES) {
+            float best = 3e38f;
+            if (n <= RT_SUB_SWEEP_MAX) {
+                int best_axis = -1, best_k = -1;
+                for (int axis = 0; axis < 3; axis++) {
+                    sorted.assign(at.begin() + lo, at.begin() + hi);
+                    std::sort(sorted.begin(), sorted.end(), [&](int a, int b) {
+                        const float ca = centroid(a, axis), cb = centroid(b, axis);
+                        return ca < cb || (ca == cb && a < b);
+                    });
+                    suffix.assign((size_t)n + 1, 0.f);
+                    float bx[6];
+                    memcpy(bx, kEmpty, sizeof(bx));
+                    for (int k = n - 1; k >= 1; k--) {
+                        grow(bx, sorted[(size_t)k]);
+                        suffix[(size_t)k] = half_area(bx);
+                    }
+                    memcpy(bx, kEmpty, sizeof(bx));
+                    for (int k = 1; k < n; k++) {  // left = the first k
+                        grow(bx, sorted[(size_t)k - 1]);
+                        const float cst = half_area(bx) * (float)k + suffix[(size_t)k] * (float)(n - k);
+                        if (cst < best) { best = cst; best_axis = axis; best_k = k; }
+                    }
+                }
+                std::sort(at.begin() + lo, at.begin() + hi, [&](int a, int b) {
+                    const float ca = centroid(a, best_axis), cb = centroid(b, best_axis);
+                    return ca < cb || (ca == cb && a < b);
+                });
+                mid = lo + best_k;
+            } else {
+                float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
+                for (int p = lo; p < hi; p++)
+                    for (int k = 0; k < 3; k++) {
+                        const float cc = centroid(at[(size_t)p], k);
+                        cmn[k] = std::min(cmn[k], cc);
+                        cmx[k] = std::max(cmx[k], cc);
+                    }
+                int axis = 0;
+                for (int k = 1; k < 3; k++)
+                    if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+                mid = lo + n / 2;
+                std::nth_element(at.begin() + lo, at.begin() + mid, at.begin() + hi, [&](int a, int b) {
+                    const float ca = centroid(a, axis), cb = centroid(b, axis);
+                    return ca < cb || (ca == cb && a < b);
+                });
+                float bl[6], br[6];
+                memcpy(bl, kEmpty, sizeof(bl));
+                memcpy(br, kEmpty, sizeof(br));
+                for (int p = lo; p < mid; p++) grow(bl, at[(size_t)p]);
+                for (int p = mid; p < hi; p++) grow(br, at[(size_t)p]);
+                best = half_area(bl) * (float)(mid - lo) + half_area(br) * (float)(hi - mid);
+            }
+            // walk n triangles, or one more node and the children's triangles weighted by how often a ray that
+            // reaches this box reaches theirs
+            const float pa = half_area(tight);
+            if (n <= RT_SUB_LEAF_MAX && !(pa > 0.f && cost_inner + best / pa < (float)n)) mid = -1;
+        }
+        if (mid < 0) {
+            if (root) return -1 - 0x40000000;  // not worth a sub-tree: the leaf stays as it is
             for (int p = lo; p < hi; p++) tflags[(size_t)p] = (unsigned char)(4 | (p == hi - 1 ? 1 : 0));
             return ~lo;
         }
-        int axis = 0;
-        for (int k = 1; k < 3; k++)
-            if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-        const int mid = lo + (hi - lo) / 2;
-        std::nth_element(at.begin() + lo, at.begin() + mid, at.begin() + hi, [&](int a, int b) {
-            const float ca = centroid(a, axis), cb = centroid(b, axis);
-            return ca < cb || (ca == cb && a < b);
-        });
         const int idx = (int)subs.size();
         subs.push_back(SubNode());
         float ba[6], bb[6];
-        const int ea = self(self, lo, mid, d + 1, ba), eb = self(self, mid, hi, d + 1, bb);
+        const int ea = self(self, lo, mid, d + 1, ba, false), eb = self(self, mid, hi, d + 1, bb, false);
         SubNode& nd = subs[(size_t)idx];
         memcpy(nd.box[0], ba, sizeof(ba));
         memcpy(nd.box[1], bb, sizeof(bb));
@@ -1323,11 +1385,13 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
             leaf_end[(size_t)first + k] = first + cnt;
         }
-        if (cnt >= big_leaf && cnt > sub_leaf && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
+        if (cnt >= big_leaf && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
             float box[6];
-            const int root = build_sub(build_sub, first, first + cnt, depth[i], box);
-            subs[(size_t)root].cnt = cnt;
-            sub_root[(size_t)i] = root;
+            const int root = build_sub(build_sub, first, first + cnt, depth[i], box, true);
+            if (root >= 0) {
+                subs[(size_t)root].cnt = cnt;
+                sub_root[(size_t)i] = root;
+            }
         }
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
