@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_REGEN_MIN 40
 #endif
 #ifndef RT_TRI_MIN
-#define RT_TRI_MIN 16  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
+#define RT_TRI_MIN 12  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
 #ifndef RT_BIG_LEAF
 #define RT_BIG_LEAF 2           // leaves with at least this many triangles may get a sub-tree (rt_device.h) ...

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's evidence -- bench line, rocprofv3 kernel stats of the same command, HBM traffic counters.
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-k='rt_render_paths_kernel<false, false, false, false>'
+k='rt_render_paths_kernel<false, true, false, false>'
 cd $root
 timeout -k 10 400 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err || exit 1
 cat gpurun_out/bench_full.json
