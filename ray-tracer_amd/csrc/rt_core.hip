@@ -217,6 +217,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_BIG_LEAF 2           // leaves with at least this many triangles may get a sub-tree (rt_device.h) ...
 #endif
 #define RT_SUB_COST_INNER 0.8f  // ... where the estimate says so: cost of a node visit in triangle tests,
+#define RT_SUB_MIN_TRIS 256     // ... in scenes of at least this many triangles (in a tiny tree the lanes of a wave walk
+                                // in step, and more kinds of step only break that up: Cornell box -10 %),
+#define RT_SUB_GAIN 1.0f        // ... by this factor at least,
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 32     // full surface-area sweep up to this many triangles, median splits above
 #ifndef RT_PATH_BATCH
@@ -1260,6 +1263,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     float cost_inner = RT_SUB_COST_INNER;
     if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(2, atoi(e));       // experiments only
     if (const char* e = getenv("RT_SUB_COST_INNER")) cost_inner = (float)atof(e);      // experiments only
+    float gain = RT_SUB_GAIN;
+    if (const char* e = getenv("RT_SUB_GAIN")) gain = (float)atof(e);                  // experiments only
+    int sub_min_tris = RT_SUB_MIN_TRIS;
+    if (const char* e = getenv("RT_SUB_MIN_TRIS")) sub_min_tris = atoi(e);             // tests: sub-trees in small scenes too
     struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
     std::vector<SubNode> subs;
     std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
@@ -1282,6 +1289,18 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         const float x = b[3] - b[0], y = b[4] - b[1], z = b[5] - b[2];
         return x * y + y * z + z * x;
     };
+    // chance that a ray which reaches a node's box reaches a child's: the ratio of the surface areas, plus the share
+    // of all rays that START on a triangle of the child (every bounce does, and then the child's box is reached for
+    // sure: what makes sub-trees over wall-sized triangles a loss)
+    std::vector<float> tri_area((size_t)std::max(ntri, 1), 0.f);
+    double total_area = 0.0;
+    for (int i = 0; i < ntri; i++) {
+        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
+        const H3 e1{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+        tri_area[(size_t)i] = 0.5f * hlen(hcross(e1, e2));
+        total_area += tri_area[(size_t)i];
+    }
+    const float inv_total_area = total_area > 0.0 ? (float)(1.0 / total_area) : 0.f;
     const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
     std::vector<int> sorted;
     std::vector<float> suffix;
@@ -1300,8 +1319,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         for (int k = 0; k < 3; k++) { box[k] -= 1e-4f * scale; box[3 + k] += 1e-4f * scale; }
         deepest = std::max(deepest, d);
         int mid = -1;
-        if (n >= 2 && d < RT_STACK_ENTRIES) {
-            float best = 3e38f;
+        const float pa = half_area(tight);
+        if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
+            float best = 3e38f;  // expected triangle tests below this node if it is split
             if (n <= RT_SUB_SWEEP_MAX) {
                 int best_axis = -1, best_k = -1;
                 for (int axis = 0; axis < 3; axis++) {
@@ -1310,17 +1330,22 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
                         const float ca = centroid(a, axis), cb = centroid(b, axis);
                         return ca < cb || (ca == cb && a < b);
                     });
-                    suffix.assign((size_t)n + 1, 0.f);
-                    float bx[6];
+                    suffix.assign(2 * ((size_t)n + 1), 0.f);  // box area and triangle area of sorted[k..n)
+                    float bx[6], ar = 0.f;
                     memcpy(bx, kEmpty, sizeof(bx));
                     for (int k = n - 1; k >= 1; k--) {
                         grow(bx, sorted[(size_t)k]);
-                        suffix[(size_t)k] = half_area(bx);
+                        ar += tri_area[(size_t)sorted[(size_t)k]];
+                        suffix[2 * (size_t)k] = half_area(bx);
+                        suffix[2 * (size_t)k + 1] = ar;
                     }
                     memcpy(bx, kEmpty, sizeof(bx));
+                    ar = 0.f;
                     for (int k = 1; k < n; k++) {  // left = the first k
                         grow(bx, sorted[(size_t)k - 1]);
-                        const float cst = half_area(bx) * (float)k + suffix[(size_t)k] * (float)(n - k);
+                        ar += tri_area[(size_t)sorted[(size_t)k - 1]];
+                        const float cst = std::min(1.f, half_area(bx) / pa + ar * inv_total_area) * (float)k +
+                                          std::min(1.f, suffix[2 * (size_t)k] / pa + suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
                         if (cst < best) { best = cst; best_axis = axis; best_k = k; }
                     }
                 }
@@ -1345,17 +1370,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
                     const float ca = centroid(a, axis), cb = centroid(b, axis);
                     return ca < cb || (ca == cb && a < b);
                 });
-                float bl[6], br[6];
+                float bl[6], br[6], al = 0.f, ar = 0.f;
                 memcpy(bl, kEmpty, sizeof(bl));
                 memcpy(br, kEmpty, sizeof(br));
-                for (int p = lo; p < mid; p++) grow(bl, at[(size_t)p]);
-                for (int p = mid; p < hi; p++) grow(br, at[(size_t)p]);
-                best = half_area(bl) * (float)(mid - lo) + half_area(br) * (float)(hi - mid);
+                for (int p = lo; p < mid; p++) { grow(bl, at[(size_t)p]); al += tri_area[(size_t)at[(size_t)p]]; }
+                for (int p = mid; p < hi; p++) { grow(br, at[(size_t)p]); ar += tri_area[(size_t)at[(size_t)p]]; }
+                best = std::min(1.f, half_area(bl) / pa + al * inv_total_area) * (float)(mid - lo) +
+                       std::min(1.f, half_area(br) / pa + ar * inv_total_area) * (float)(hi - mid);
             }
-            // walk n triangles, or one more node and the children's triangles weighted by how often a ray that
-            // reaches this box reaches theirs
-            const float pa = half_area(tight);
-            if (n <= RT_SUB_LEAF_MAX && !(pa > 0.f && cost_inner + best / pa < (float)n)) mid = -1;
+            // walk n triangles, or one more node and the triangles of the children that are reached
+            if (n <= RT_SUB_LEAF_MAX && !(cost_inner + best < gain * (float)n)) mid = -1;
         }
         if (mid < 0) {
             if (root) return -1 - 0x40000000;  // not worth a sub-tree: the leaf stays as it is
@@ -1385,7 +1409,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
             leaf_end[(size_t)first + k] = first + cnt;
         }
-        if (cnt >= big_leaf && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
+        if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
             float box[6];
             const int root = build_sub(build_sub, first, first + cnt, depth[i], box, true);
             if (root >= 0) {

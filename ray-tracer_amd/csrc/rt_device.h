@@ -358,6 +358,8 @@ struct Trav {
     int sp;       // entries on this lane's LDS stack
     int hitTri;   // place of the hit triangle in the item stream (Scene::tri_id gives hitTriIndex / 25), or -1
     float slack;  // sub-tree pruning: bound on the rounding error of a squared distance from this origin
+    float subLim; // minD2 with that slack: what a sub-tree node's squared distance is compared with
+    __device__ __forceinline__ void set_min(float m) { minD2 = m; subLim = m * 1.00002f + slack; }
     float minD2;  // minDistSqr, main.cu:223
     float hitT;   // ray parameter of the closest hit: its position o + d * hitT is formed again when the query is
                   // over (same operands, same operations as main.cu:66 -> same bits) instead of being carried along
@@ -379,7 +381,7 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d,
         const float osum = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
         t.slack = 1e-5f * osum * osum;
     }
-    t.minD2 = minD2_0;  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
+    t.set_min(minD2_0);  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
     // `AABBIntersectDistance(...) < 1e12` compares float with the DOUBLE 1e12 (main.cu:234):
     // true up to and including the float nearest below 1e12, i.e. f <= 1e12f.
@@ -490,7 +492,7 @@ __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, flo
     const float dNear = aNear ? dA : dB, dFar = aNear ? dB : dA;
     // the reference's rule for its own nodes; inside a sub-tree a child is skipped only if no triangle in its
     // (padded) box can come out at or below minD2, whatever the rounding of either squared distance
-    const float lim = sub ? t.minD2 * 1.00002f + t.slack : t.minD2;
+    const float lim = sub ? t.subLim : t.minD2;
     if (dFar < lim) { stk[t.sp * 64] = eFar; t.sp++; }
     if (dNear < lim) t.cur = eNear;
     else trav_pop(t, stk);
@@ -516,7 +518,7 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
         const f3 pos = o + t.d * ht;
         const float nd = len2(pos - o);
         if (nd < t.minD2 || (SUB && nd == t.minD2 && tie_replaces(sc, t.hitTri, q2, false))) {
-            t.minD2 = nd;
+            t.set_min(nd);
             t.set_hit(ht, pos);
             t.hitTri = item - sc.n_inner;
         }
@@ -588,7 +590,7 @@ __device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Count
             const f3 pos = o + t.d * ht;
             const float nd = len2(pos - o);
             if (nd < t.minD2 || (sc.n_sub > 0 && nd == t.minD2 && tie_replaces(sc, t.hitTri, h2, true))) {
-                t.minD2 = nd;
+                t.set_min(nd);
                 t.set_hit(ht, pos);
                 t.hitTri = i;
             }

@@ -274,10 +274,10 @@ def test_sample_chunks_of_the_path_kernel(ob, rt, gpu, scenes, monkeypatch):
 
 
 @pytest.mark.parametrize("depth", [2, 5, 8])
-def test_big_leaves_whole_wave_test(ob, rt, gpu, depth):
-    """Shallow trees over scene.txt / a small dragon field: leaves of 48 triangles and more are tested by the whole
-    wave in the path kernel (64 triangles per step, several owners per leaf).  Sums and counters as the oracle's
-    and the one-triangle-per-step kernels'; leaves of 47 and fewer keep the per-lane walk in the same run."""
+def test_big_leaves_get_sub_trees(ob, rt, gpu, depth):
+    """Shallow trees over scene.txt: leaves of hundreds of triangles, which the device walks through a small tree
+    of its own per leaf (triangles reordered inside the leaf, padded boxes, pruning with slack, ties by triangle
+    id).  Sums and counters as the oracle's plain walk over every triangle of the leaf, in all three schedules."""
     sc = rt.Scene.load("scene.txt", bvh_max_depth=depth)
     gpu.upload(sc)
     p = rt.default_params(sc.camera, spp=3, width=72, height=56, max_bounces=5, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
@@ -495,3 +495,46 @@ def test_config4_field_at_full_size(ob, rt, gpu):
     gpu.reset(); st_c = gpu.render(c); crop = gpu.readback()
     o, ost = ob.render(sc, c, n_threads=16)
     assert np.array_equal(crop, o) and (st_c.rays, st_c.tri_tests) == (ost.rays, ost.tri_tests)
+
+
+def test_sub_tree_ties_go_to_the_first_triangle(ob, rt, gpu, monkeypatch):
+    """Coincident triangles (every triangle eight times, copies far apart in the array, each copy with another
+    material) in leaves big enough for sub-trees: the reference keeps the FIRST of several triangles at the same
+    distance, the sub-tree meets them in its own order and has to pick by id.  Hit ids, images and counters against
+    the oracle's walk; with sub-trees forced on (tiny scene) and off."""
+    rng = np.random.default_rng(5)
+    base = rng.normal(0, 1.0, (24, 1, 3)) + np.array([0, 0, -6.0]) + rng.normal(0, 0.6, (24, 3, 3))
+    order = rng.permutation(np.repeat(np.arange(24), 8))
+    n = len(order)
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = base[order].reshape(n, 9)
+    nr = rng.normal(0, 1, (n, 3, 3)); nr /= np.linalg.norm(nr, axis=2, keepdims=True)
+    t[:, 9:18] = nr.reshape(n, 9)
+    t[:, 18:24] = rng.uniform(0, 0.999, (n, 6))
+    mats = []
+    for k in range(8):
+        m = rt.Material(); m.type = [3, 1, 0, 4, 3, 5, 1, 3][k]; m.color = int(rng.integers(0, 1 << 24)); m.p1 = 0.8; m.p2 = 0.2
+        m.image_offset[:] = [-1, -1, -1]
+        mats.append(m)
+    t[:, 24] = np.arange(n) % 8 + 0.001
+    sc = rt.Scene.from_records(t, mats, bvh_max_depth=2, bvh_min_tris=1)
+    rays = np.zeros((4000, 6), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.3, (4000, 3))
+    tgt = base[rng.integers(0, 24, 4000)].mean(1) + rng.normal(0, 0.3, (4000, 3))
+    d = tgt - rays[:, 0:3]
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    oprim, ot = ob.trace_rays(sc, rays)[:2]
+    assert (oprim >= 0).sum() > 1000
+    p = rt.default_params(sc.camera, spp=2, width=64, height=48, max_bounces=4, flags=rt.F_BVH | rt.F_STATS)
+    o, ost = ob.render(sc, p, n_threads=8)
+    for min_tris in ("0", "1000000"):
+        monkeypatch.setenv("RT_SUB_MIN_TRIS", min_tris)
+        gpu.upload(sc)
+        gprim, gt = gpu.trace_rays(rays, rt.F_BVH)[:2]
+        assert np.array_equal(gprim, oprim) and np.array_equal(gt, ot), min_tris
+        assert np.array_equal(gpu.trace_rays(rays, 0)[0], ob.trace_rays(sc, rays, 0)[0]), min_tris   # brute force: ties over the whole array
+        for mode in ("megakernel", "lockstep", "wavefront"):
+            q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
+            gpu.reset(); st = gpu.render(q)
+            assert np.array_equal(gpu.readback(), o), (min_tris, mode)
+            assert (st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == (ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
