@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt.h"
@@ -1268,7 +1269,6 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     int sub_min_tris = RT_SUB_MIN_TRIS;
     if (const char* e = getenv("RT_SUB_MIN_TRIS")) sub_min_tris = atoi(e);             // tests: sub-trees in small scenes too
     struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
-    std::vector<SubNode> subs;
     std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
     std::vector<int> leaf_end((size_t)std::max(ntri, 1), 0), sub_root((size_t)std::max(nn, 1), -1);
     std::vector<unsigned char> tflags((size_t)std::max(ntri, 1), 0);
@@ -1302,13 +1302,14 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     const float inv_total_area = total_area > 0.0 ? (float)(1.0 / total_area) : 0.f;
     const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
-    std::vector<int> sorted;
-    std::vector<float> suffix;
-    int deepest = max_depth;  // of the whole structure: sizes the traversal stack
-    // One node of a sub-tree over the triangles at places [lo, hi), d = its depth in the whole structure.  Splits
-    // by the surface-area heuristic (sweep over the three axes for small sets, median of the widest axis above),
-    // and stops where the walk over the triangles is estimated cheaper than another node.  Returns the child entry.
-    auto build_sub = [&](auto&& self, int lo, int hi, int d, float* box, bool root) -> int {
+    struct SubWork {  // what one host thread builds: leaves are independent (each reorders its own range of `at`)
+        std::vector<SubNode> subs;
+        std::vector<int> sorted;
+        std::vector<float> suffix;
+        std::vector<std::pair<int, int>> roots;  // (leaf node, root in subs)
+        int deepest = 0;
+    };
+    auto build_sub = [&](auto&& self, SubWork& w, int lo, int hi, int d, float* box, bool root) -> int {
         const int n = hi - lo;
         float tight[6];
         memcpy(tight, kEmpty, sizeof(tight));
@@ -1317,7 +1318,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         float scale = 1.f;  // pad: a sub-tree box must never make the ray miss a triangle it hits
         for (int k = 0; k < 6; k++) scale = std::max(scale, std::fabs(box[k]));
         for (int k = 0; k < 3; k++) { box[k] -= 1e-4f * scale; box[3 + k] += 1e-4f * scale; }
-        deepest = std::max(deepest, d);
+        w.deepest = std::max(w.deepest, d);
         int mid = -1;
         const float pa = half_area(tight);
         if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
@@ -1325,27 +1326,27 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             if (n <= RT_SUB_SWEEP_MAX) {
                 int best_axis = -1, best_k = -1;
                 for (int axis = 0; axis < 3; axis++) {
-                    sorted.assign(at.begin() + lo, at.begin() + hi);
-                    std::sort(sorted.begin(), sorted.end(), [&](int a, int b) {
+                    w.sorted.assign(at.begin() + lo, at.begin() + hi);
+                    std::sort(w.sorted.begin(), w.sorted.end(), [&](int a, int b) {
                         const float ca = centroid(a, axis), cb = centroid(b, axis);
                         return ca < cb || (ca == cb && a < b);
                     });
-                    suffix.assign(2 * ((size_t)n + 1), 0.f);  // box area and triangle area of sorted[k..n)
+                    w.suffix.assign(2 * ((size_t)n + 1), 0.f);  // box area and triangle area of w.sorted[k..n)
                     float bx[6], ar = 0.f;
                     memcpy(bx, kEmpty, sizeof(bx));
                     for (int k = n - 1; k >= 1; k--) {
-                        grow(bx, sorted[(size_t)k]);
-                        ar += tri_area[(size_t)sorted[(size_t)k]];
-                        suffix[2 * (size_t)k] = half_area(bx);
-                        suffix[2 * (size_t)k + 1] = ar;
+                        grow(bx, w.sorted[(size_t)k]);
+                        ar += tri_area[(size_t)w.sorted[(size_t)k]];
+                        w.suffix[2 * (size_t)k] = half_area(bx);
+                        w.suffix[2 * (size_t)k + 1] = ar;
                     }
                     memcpy(bx, kEmpty, sizeof(bx));
                     ar = 0.f;
                     for (int k = 1; k < n; k++) {  // left = the first k
-                        grow(bx, sorted[(size_t)k - 1]);
-                        ar += tri_area[(size_t)sorted[(size_t)k - 1]];
+                        grow(bx, w.sorted[(size_t)k - 1]);
+                        ar += tri_area[(size_t)w.sorted[(size_t)k - 1]];
                         const float cst = std::min(1.f, half_area(bx) / pa + ar * inv_total_area) * (float)k +
-                                          std::min(1.f, suffix[2 * (size_t)k] / pa + suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
+                                          std::min(1.f, w.suffix[2 * (size_t)k] / pa + w.suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
                         if (cst < best) { best = cst; best_axis = axis; best_k = k; }
                     }
                 }
@@ -1386,11 +1387,11 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             for (int p = lo; p < hi; p++) tflags[(size_t)p] = (unsigned char)(4 | (p == hi - 1 ? 1 : 0));
             return ~lo;
         }
-        const int idx = (int)subs.size();
-        subs.push_back(SubNode());
+        const int idx = (int)w.subs.size();
+        w.subs.push_back(SubNode());
         float ba[6], bb[6];
-        const int ea = self(self, lo, mid, d + 1, ba, false), eb = self(self, mid, hi, d + 1, bb, false);
-        SubNode& nd = subs[(size_t)idx];
+        const int ea = self(self, w, lo, mid, d + 1, ba, false), eb = self(self, w, mid, hi, d + 1, bb, false);
+        SubNode& nd = w.subs[(size_t)idx];
         memcpy(nd.box[0], ba, sizeof(ba));
         memcpy(nd.box[1], bb, sizeof(bb));
         nd.e[0] = ea;
@@ -1398,6 +1399,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         nd.cnt = 0;
         return idx;
     };
+    std::vector<int> candidates;
     for (int i = 0; i < nn; i++) {
         const rt_bvh_node& n = s->nodes[i];
         if (n.child_a != -1) continue;
@@ -1409,14 +1411,46 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
             leaf_end[(size_t)first + k] = first + cnt;
         }
-        if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) {  // (the traversal stack has room below this leaf)
-            float box[6];
-            const int root = build_sub(build_sub, first, first + cnt, depth[i], box, true);
-            if (root >= 0) {
-                subs[(size_t)root].cnt = cnt;
-                sub_root[(size_t)i] = root;
+        // (the traversal stack must have room below this leaf)
+        if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
+    }
+    int n_workers = 1;
+    if (candidates.size() >= 4096) {
+        n_workers = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("RT_HOST_THREADS")) n_workers = std::min(16, std::max(1, atoi(e)));
+    }
+    std::vector<SubWork> work((size_t)n_workers);
+    {
+        auto run = [&](int wi) {
+            SubWork& w = work[(size_t)wi];
+            const size_t lo = candidates.size() * (size_t)wi / (size_t)n_workers, hi = candidates.size() * (size_t)(wi + 1) / (size_t)n_workers;
+            for (size_t ci = lo; ci < hi; ci++) {
+                const int i = candidates[ci];
+                const int first = s->nodes[i].tri_offs / RT_TRI_FLOATS, cnt = s->nodes[i].tri_len / RT_TRI_FLOATS;
+                float box[6];
+                const int root = build_sub(build_sub, w, first, first + cnt, depth[i], box, true);
+                if (root >= 0) {
+                    w.subs[(size_t)root].cnt = cnt;
+                    w.roots.push_back({i, root});
+                }
             }
+        };
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < n_workers; wi++) th.emplace_back(run, wi);
+        run(0);
+        for (auto& t : th) t.join();
+    }
+    std::vector<SubNode> subs;  // the workers' nodes one after the other (contiguous leaf ranges: same order as one thread's)
+    int deepest = max_depth;    // of the whole structure: sizes the traversal stack
+    for (SubWork& w : work) {
+        const int off = (int)subs.size();
+        for (SubNode nd : w.subs) {
+            for (int k = 0; k < 2; k++)
+                if (nd.e[k] >= 0) nd.e[k] += off;
+            subs.push_back(nd);
         }
+        for (const auto& r : w.roots) sub_root[(size_t)r.first] = off + r.second;
+        deepest = std::max(deepest, w.deepest);
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
     n_inner = n_top + n_sub;
