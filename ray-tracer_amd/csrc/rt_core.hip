@@ -52,8 +52,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES)  // item i>>2, piece i&3 (coalesced read)
-        rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
-    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+        rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
+    int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                                                                               unsigned int n_paths) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
-    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
+    int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -725,8 +725,8 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
     const unsigned int n_rays = *n_rays_ptr;
     if ((unsigned long long)blockIdx.x * RT_TRACE_WAVES * 64 >= n_rays) return;  // no wave of this block has a first chunk
     for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_TRACE_WAVES)  // item i>>2, piece i&3 (coalesced read)
-        rt_lds[(i & 3) * n_cached + (i >> 2)] = sc.items[i];
-    int* stk = (int*)(rt_lds + 4 * (size_t)n_cached) + (size_t)wave * stack_entries * 64 + lane;
+        rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
+    int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     __syncthreads();
     const bool use_bvh = (flags & RT_F_BVH) != 0;
     const bool spheres_on = (flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -1452,6 +1452,39 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         for (const auto& r : w.roots) sub_root[(size_t)r.first] = off + r.second;
         deepest = std::max(deepest, w.deepest);
     }
+    {   // order the sub-tree nodes by level, big boxes first: the node cache in LDS takes the items from the front
+        const size_t ns = subs.size();
+        std::vector<int> level(ns, 0), perm(ns), inv(ns);
+        std::vector<float> area(ns, 0.f);
+        for (size_t j = 0; j < ns; j++) {  // (children come after their parent in a worker's list)
+            const SubNode& nd = subs[j];
+            float u[6];
+            for (int k = 0; k < 3; k++) {
+                u[k] = std::min(nd.box[0][k], nd.box[1][k]);
+                u[3 + k] = std::max(nd.box[0][3 + k], nd.box[1][3 + k]);
+            }
+            area[j] = half_area(u);
+            for (int k = 0; k < 2; k++)
+                if (nd.e[k] >= 0) level[(size_t)nd.e[k]] = level[j] + 1;
+            perm[j] = (int)j;
+        }
+        std::sort(perm.begin(), perm.end(), [&](int a, int b) {
+            if (level[(size_t)a] != level[(size_t)b]) return level[(size_t)a] < level[(size_t)b];
+            if (area[(size_t)a] != area[(size_t)b]) return area[(size_t)a] > area[(size_t)b];
+            return a < b;
+        });
+        for (size_t j = 0; j < ns; j++) inv[(size_t)perm[j]] = (int)j;
+        std::vector<SubNode> ordered(ns);
+        for (size_t j = 0; j < ns; j++) {
+            SubNode nd = subs[(size_t)perm[j]];
+            for (int k = 0; k < 2; k++)
+                if (nd.e[k] >= 0) nd.e[k] = inv[(size_t)nd.e[k]];
+            ordered[j] = nd;
+        }
+        subs.swap(ordered);
+        for (int& r : sub_root)
+            if (r >= 0) r = inv[(size_t)r];
+    }
     const int n_top = n_inner, n_sub = (int)subs.size();
     n_inner = n_top + n_sub;
     if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
@@ -1675,10 +1708,10 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES) {
     t.stack_entries = std::max(c->bvh_depth, 1);
     const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int);
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
-    size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / 64 : 0;
+    size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
     t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)c->sc.n_inner);
-    t.lds_bytes = (size_t)t.n_cached * 64 + stack_bytes;
+    t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
     t.grid = c->num_cus;
     return t;
 }

@@ -406,10 +406,25 @@ __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
 // volatile + explicit address space: keeps these four ds_read_b128 apart from global loads (without it
 // the compiler merges both sides into FLAT loads through a selected generic pointer, split into eleven
 // narrower loads per step).
+#ifndef RT_LDS_REC
+#define RT_LDS_REC 5  // float4s per cached item: 4 pieces + 1 of padding (0 = four piece arrays, n_cached float4s apart)
+#endif
+#if RT_LDS_REC
+#define RT_LDS_SLOT(item, piece, n_cached) ((int)__umul24((unsigned)(item), RT_LDS_REC) + (piece))  // (v_mul_u32_u24: full rate)
+#define RT_LDS_CACHE_FLOAT4S(n_cached) ((size_t)RT_LDS_REC * (size_t)(n_cached))
+#else
+#define RT_LDS_SLOT(item, piece, n_cached) ((piece) * (n_cached) + (item))
+#define RT_LDS_CACHE_FLOAT4S(n_cached) ((size_t)4 * (size_t)(n_cached))
+#endif
 __device__ __forceinline__ void load_cached_item(int item, int n_cached, float4& q0, float4& q1, float4& q2, float4& q3) {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    const volatile __attribute__((address_space(3))) v4f* c = (const volatile __attribute__((address_space(3))) v4f*)rt_lds;
-    const v4f a0 = c[item], a1 = c[n_cached + item], a2 = c[2 * n_cached + item], a3 = c[3 * n_cached + item];
+    typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f;
+    const lds_v4f c = (lds_v4f)rt_lds;
+    // records of 80 bytes: ONE address (item * 80) and four ds_read_b128 with immediate offsets; the odd stride in
+    // 16-byte units spreads the items over all 16 bank groups like separate piece arrays would, without their three
+    // extra uniform strides (which the compiler had no scalar registers left for: v_readlane from a spill VGPR per step)
+    const v4f a0 = c[RT_LDS_SLOT(item, 0, n_cached)], a1 = c[RT_LDS_SLOT(item, 1, n_cached)], a2 = c[RT_LDS_SLOT(item, 2, n_cached)],
+              a3 = c[RT_LDS_SLOT(item, 3, n_cached)];
     q0 = make_float4(a0.x, a0.y, a0.z, a0.w);
     q1 = make_float4(a1.x, a1.y, a1.z, a1.w);
     q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
