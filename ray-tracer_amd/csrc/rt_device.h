@@ -406,6 +406,9 @@ __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
 // volatile + explicit address space: keeps these four ds_read_b128 apart from global loads (without it
 // the compiler merges both sides into FLAT loads through a selected generic pointer, split into eleven
 // narrower loads per step).
+#ifndef RT_TRI_LOAD_PIN
+#define RT_TRI_LOAD_PIN 1
+#endif
 #ifndef RT_LDS_REC
 #define RT_LDS_REC 5  // float4s per cached item: 4 pieces + 1 of padding (0 = four piece arrays, n_cached float4s apart)
 #endif
@@ -587,7 +590,14 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
         return;
     }
     const float4* w = sc.items + 4 * (size_t)t.cur;
-    visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, w[0], w[1], w[2]);
+    float4 q0 = w[0], q1 = w[1], q2 = w[2];
+#if RT_TRI_LOAD_PIN
+    // three aligned 16-byte loads issued together: left alone, the compiler sinks the load of v0 behind the
+    // determinant test (a second memory latency in most steps) and fetches the rest as unaligned pieces
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y),
+                 "+v"(q2.z), "+v"(q2.w));
+#endif
+    visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
 }
 
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
