@@ -406,6 +406,9 @@ __device__ __forceinline__ void trav_pop(Trav& t, const int* stk) {
 // volatile + explicit address space: keeps these four ds_read_b128 apart from global loads (without it
 // the compiler merges both sides into FLAT loads through a selected generic pointer, split into eleven
 // narrower loads per step).
+#ifndef RT_INNER_LOAD_PIN
+#define RT_INNER_LOAD_PIN 1
+#endif
 #ifndef RT_TRI_LOAD_PIN
 #define RT_TRI_LOAD_PIN 1
 #endif
@@ -578,6 +581,9 @@ __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* s
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
+#if RT_INNER_LOAD_PIN
+        asm volatile("" : "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));  // (one 16-byte load, not a 16-byte and a 4-byte one)
+#endif
     }
     visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
 }
