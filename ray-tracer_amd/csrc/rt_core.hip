@@ -221,6 +221,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_SUB_MIN_TRIS 256     // ... in scenes of at least this many triangles (in a tiny tree the lanes of a wave walk
                                 // in step, and more kinds of step only break that up: Cornell box -10 %),
 #define RT_SUB_GAIN 1.0f        // ... by this factor at least,
+#define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 32     // full surface-area sweep up to this many triangles, median splits above
 #ifndef RT_PATH_BATCH
@@ -1294,13 +1295,22 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     // sure: what makes sub-trees over wall-sized triangles a loss)
     std::vector<float> tri_area((size_t)std::max(ntri, 1), 0.f);
     double total_area = 0.0;
+    float scene_scale = 0.f;  // largest |coordinate| of the scene
     for (int i = 0; i < ntri; i++) {
         const float* t = tris + (size_t)i * RT_TRI_FLOATS;
+        for (int k = 0; k < 9; k++) scene_scale = std::max(scene_scale, std::fabs(t[k]));
         const H3 e1{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
         tri_area[(size_t)i] = 0.5f * hlen(hcross(e1, e2));
         total_area += tri_area[(size_t)i];
     }
     const float inv_total_area = total_area > 0.0 ? (float)(1.0 / total_area) : 0.f;
+    if (!(scene_scale > 0.f) || !(scene_scale < 1e30f)) scene_scale = 1.f;
+    // Boxes this library adds (sub-trees, light groups) are padded by 1e-5 of the scene's scale S (largest |coordinate|),
+    // and cull only for rays that start within RT_CULL_FAR x S of the origin on every axis.  The slab test forms
+    // (bound - o) * (1 / d): a few ulp of the distance to the box, at most 4 x 1.2e-7 x (8 S + S) = 4.5e-6 S for such
+    // a ray -- and the triangle test is blurred by as much.  Rays from farther away test every triangle of a leaf,
+    // as the reference does.
+    const float box_pad = 1e-5f * scene_scale;
     const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
     struct SubWork {  // what one host thread builds: leaves are independent (each reorders its own range of `at`)
         std::vector<SubNode> subs;
@@ -1315,9 +1325,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         memcpy(tight, kEmpty, sizeof(tight));
         for (int p = lo; p < hi; p++) grow(tight, at[(size_t)p]);
         memcpy(box, tight, sizeof(tight));
-        float scale = 1.f;  // pad: a sub-tree box must never make the ray miss a triangle it hits
-        for (int k = 0; k < 6; k++) scale = std::max(scale, std::fabs(box[k]));
-        for (int k = 0; k < 3; k++) { box[k] -= 1e-4f * scale; box[3 + k] += 1e-4f * scale; }
+        for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }  // a sub-tree box must never make the ray miss a triangle it hits
         w.deepest = std::max(w.deepest, d);
         int mid = -1;
         const float pa = half_area(tight);
@@ -1588,11 +1596,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     for (int g = 0; g < n_light_groups && s->n_light_tris > 0; g++) {  // pad: the culling test must never say no wrongly
         float* B = &lights[light_box_off + (size_t)g * 8];
-        float scale = 1.f;
-        for (int k = 0; k < 3; k++) scale = std::max(scale, std::max(std::fabs(B[k]), std::fabs(B[4 + k])));
         for (int k = 0; k < 3; k++) {
-            B[k] -= 1e-4f * scale;
-            B[4 + k] += 1e-4f * scale;
+            B[k] -= box_pad;
+            B[4 + k] += box_pad;
         }
     }
 
@@ -1621,6 +1627,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.tri_place = (const int*)c->d_place;
     sc.n_inner = n_inner;
     sc.n_sub = n_sub;
+    sc.cull_far = RT_CULL_FAR * scene_scale;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;

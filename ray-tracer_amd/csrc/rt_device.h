@@ -65,6 +65,7 @@ struct Scene {
     long long n_tex;
     int n_inner;      // inner items: the reference's nodes, then the sub-tree nodes
     int n_sub;        // sub-tree nodes among them (0: every triangle is at its reference place)
+    float cull_far;   // rays that start farther than this from the origin (any axis) are not culled by padded boxes
     int n_tris;
     int n_mats;
     int n_lights;
@@ -379,7 +380,9 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d,
     t.hitTri = -1;
     {   // |fl(o + d t) - o|^2 is off by ~2 dist E, E = a few ulp of (|o| + dist); 2 dist E <= 4e-7 (|o|_1^2 + 3 dist^2)
         const float osum = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
-        t.slack = 1e-5f * osum * osum;
+        // from very far away the slab test itself is coarser than the padding: infinite slack = every node of a
+        // sub-tree is visited (its boxes still order the children), i.e. the reference's walk over the whole leaf
+        t.slack = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.cull_far ? 1e-5f * osum * osum : INFINITY;
     }
     t.set_min(minD2_0);  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));
@@ -982,9 +985,14 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
         const int n_groups = min(64, (sc.n_lights - base + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP);
         const float4* B = sc.light_boxes + 2 * (base / RT_LIGHT_GROUP);
         unsigned long long mine = 0;
-        if (q.pending)
-            for (int g = 0; g < n_groups; g++)
-                if (br.may_reach(B[2 * g], B[2 * g + 1])) mine |= 1ull << g;
+        if (q.pending) {
+            if (fmaxf(fabsf(q.hitPos.x), fmaxf(fabsf(q.hitPos.y), fabsf(q.hitPos.z))) <= sc.cull_far) {
+                for (int g = 0; g < n_groups; g++)
+                    if (br.may_reach(B[2 * g], B[2 * g + 1])) mine |= 1ull << g;
+            } else {  // too far out for the padding of the boxes to cover the rounding of the slab test: every group
+                mine = n_groups >= 64 ? ~0ull : (1ull << n_groups) - 1;
+            }
+        }
         for (unsigned long long m = __ballot(mine != 0); m; m &= m - 1) {
             const int ow = __ffsll((long long)m) - 1;
             const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));

@@ -538,3 +538,32 @@ def test_sub_tree_ties_go_to_the_first_triangle(ob, rt, gpu, monkeypatch):
             gpu.reset(); st = gpu.render(q)
             assert np.array_equal(gpu.readback(), o), (min_tris, mode)
             assert (st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == (ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
+
+
+@pytest.mark.parametrize("scale,dist", [(1e-3, 1.0), (1.0, 3e4), (1e3, 10.0), (50.0, 1.5e4), (1.0, 0.0)])
+def test_sub_trees_at_extreme_scales(ob, rt, gpu, monkeypatch, scale, dist):
+    """The sub-tree boxes are padded by 1e-4 max(1, |coordinate|) and pruned with a slack that grows with |origin|^2:
+    tiny scenes (the padding swallows them), huge ones, origins very far from the geometry (squared distances lose
+    their low bits) and origins inside it.  Closest hits as the oracle's walk over every triangle of the leaf."""
+    rng = np.random.default_rng(int(scale * 7 + dist) % 1000)
+    n = 1200
+    c = rng.normal(0, 1.0, (n, 1, 3))
+    v = (c + rng.normal(0, 0.08, (n, 3, 3))) * scale
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = v.reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1.0], (n, 3))
+    m = rt.Material(); m.type = 3; m.color = 0x808080; m.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(t, [m], bvh_max_depth=3, bvh_min_tris=1)     # 8 leaves of ~150 triangles
+    nr = 6000
+    d0 = rng.normal(0, 1, (nr, 3)); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    org = d0 * dist * scale + rng.normal(0, 0.3 * scale, (nr, 3))
+    tgt = rng.normal(0, 0.7 * scale, (nr, 3))
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    gpu.upload(sc)
+    gp, gt, gpos = gpu.trace_rays(rays, rt.F_BVH)[:3]
+    op, ot, opos = ob.trace_rays(sc, rays, rt.F_BVH)[:3]
+    assert (op >= 0).sum() > nr // 20
+    assert np.array_equal(gp, op) and np.array_equal(gt, ot) and np.array_equal(gpos, opos)
