@@ -360,7 +360,8 @@ struct Trav {
     int hitTri;   // place of the hit triangle in the item stream (Scene::tri_id gives hitTriIndex / 25), or -1
     float slack;  // sub-tree pruning: bound on the rounding error of a squared distance from this origin
     float subLim; // minD2 with that slack: what a sub-tree node's squared distance is compared with
-    __device__ __forceinline__ void set_min(float m) { minD2 = m; subLim = m * 1.00002f + slack; }
+    float invD2;  // 1 / |d|^2, a little up: the reference compares t^2 of a box with |d t|^2 of a hit (equal for unit directions)
+    __device__ __forceinline__ void set_min(float m) { minD2 = m; subLim = (m * 1.00002f + slack) * invD2; }
     float minD2;  // minDistSqr, main.cu:223
     float hitT;   // ray parameter of the closest hit: its position o + d * hitT is formed again when the query is
                   // over (same operands, same operations as main.cu:66 -> same bits) instead of being carried along
@@ -383,6 +384,7 @@ __device__ __forceinline__ void trav_begin(const Scene& sc, Trav& t, f3 o, f3 d,
         // from very far away the slab test itself is coarser than the padding: infinite slack = every node of a
         // sub-tree is visited (its boxes still order the children), i.e. the reference's walk over the whole leaf
         t.slack = fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.cull_far ? 1e-5f * osum * osum : INFINITY;
+        t.invD2 = 1.00001f / len2(d);
     }
     t.set_min(minD2_0);  // 1e12, or |marchVelocity|^2 under ENABLE_RAY_MARCHING (main.cu:223-227)
     t.set_hit(0.0f, mk(0.f, 0.f, 0.f));

@@ -560,6 +560,7 @@ def test_sub_trees_at_extreme_scales(ob, rt, gpu, monkeypatch, scale, dist):
     tgt = rng.normal(0, 0.7 * scale, (nr, 3))
     d = tgt - org
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[nr // 2:] *= rng.uniform(0.2, 4.0, (nr - nr // 2, 1))              # callers' rays need not be unit vectors
     rays = np.concatenate([org, d], axis=1).astype(np.float32)
     monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
     gpu.upload(sc)
