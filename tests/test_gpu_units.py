@@ -568,3 +568,65 @@ def test_sub_trees_at_extreme_scales(ob, rt, gpu, monkeypatch, scale, dist):
     op, ot, opos = ob.trace_rays(sc, rays, rt.F_BVH)[:3]
     assert (op >= 0).sum() > nr // 20
     assert np.array_equal(gp, op) and np.array_equal(gt, ot) and np.array_equal(gpos, opos)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_sub_tree_stress_against_the_full_walk(ob, rt, gpu, monkeypatch, seed):
+    """Rays chosen to sit on the edges of the sub-tree arithmetic: origins ON triangles (bounce rays start there),
+    at vertices and on box faces, directions along the axes and inside the planes of axis-aligned quads, grazing
+    rays.  Geometry: a random soup (seeds 0-2) or a lattice of axis-aligned quads whose boxes are flat (3-5).
+    Ids, distances and positions must equal the oracle's, which tests every triangle of every leaf it visits."""
+    rng = np.random.default_rng(900 + seed)
+    if seed < 3:
+        n = 2000
+        c = rng.uniform(-2, 2, (n, 1, 3))
+        v = c + rng.normal(0, rng.choice([0.03, 0.15, 0.6]), (n, 3, 3))
+    else:
+        quads = []
+        g = np.arange(-3, 4) * 0.5
+        for axis in range(3):
+            for a in g:
+                for b in g[::2]:
+                    for h in g[::3]:
+                        p0 = np.zeros(3); p0[axis] = h; p0[(axis + 1) % 3] = a; p0[(axis + 2) % 3] = b
+                        e1 = np.zeros(3); e1[(axis + 1) % 3] = 0.5
+                        e2 = np.zeros(3); e2[(axis + 2) % 3] = 1.0
+                        quads += [[p0, p0 + e1, p0 + e1 + e2], [p0, p0 + e1 + e2, p0 + e2]]
+        v = np.array(quads)
+        v = v[rng.permutation(len(v))]
+        n = len(v)
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = v.reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1.0], (n, 3))
+    m = rt.Material(); m.type = 3; m.color = 0x808080; m.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(t, [m], bvh_max_depth=int(rng.choice([1, 3, 6])), bvh_min_tris=1)
+    vf = t[:, 0:9].reshape(n, 3, 3).astype(np.float64)
+    k = 5000
+    pick = rng.integers(0, n, k)
+    bary = rng.dirichlet([1, 1, 1], k)
+    on_tri = np.einsum("kj,kjc->kc", bary, vf[pick])                       # points on triangles
+    at_vertex = vf[pick, rng.integers(0, 3, k)]                             # triangle vertices
+    dirs = rng.normal(0, 1, (k, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    axis_dirs = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1))
+    in_plane = dirs.copy(); in_plane[np.arange(k), rng.integers(0, 3, k)] = 0.0   # inside an axis-aligned plane
+    in_plane /= np.maximum(np.linalg.norm(in_plane, axis=1, keepdims=True), 1e-9)
+    target = np.einsum("kj,kjc->kc", rng.dirichlet([1, 1, 1], k), vf[rng.integers(0, n, k)])
+    far = rng.normal(0, 6, (k, 3))
+    toward = target - far; toward /= np.linalg.norm(toward, axis=1, keepdims=True)
+    rays = np.concatenate([
+        np.concatenate([on_tri + 1e-5 * dirs, dirs], 1),        # bounce-like
+        np.concatenate([on_tri, axis_dirs], 1),                 # from a surface along an axis
+        np.concatenate([at_vertex, dirs], 1),                   # from a vertex (on the corner of some box)
+        np.concatenate([at_vertex, in_plane], 1),               # from a vertex inside an axis plane
+        np.concatenate([far, toward], 1),                       # aimed at a point of a triangle from outside
+        np.concatenate([np.round(far * 2) / 2, axis_dirs], 1),  # lattice origins along the axes (in the quads' planes)
+    ]).astype(np.float32)
+    op, ot, opos = ob.trace_rays(sc, rays, rt.F_BVH)[:3]
+    assert (op >= 0).sum() > len(rays) // 10
+    for min_tris in ("0", "1000000"):
+        monkeypatch.setenv("RT_SUB_MIN_TRIS", min_tris)
+        gpu.upload(sc)
+        gp, gt, gpos = gpu.trace_rays(rays, rt.F_BVH)[:3]
+        bad = np.flatnonzero(gp != op)
+        assert bad.size == 0, (min_tris, bad[:10], gp[bad[:10]], op[bad[:10]])
+        assert np.array_equal(gt, ot) and np.array_equal(gpos, opos), min_tris
