@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_SUB_GAIN 1.0f        // ... by this factor at least,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
-#define RT_SUB_SWEEP_MAX 32     // full surface-area sweep up to this many triangles, median splits above
+#define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
 #endif
@@ -1267,6 +1267,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (const char* e = getenv("RT_SUB_COST_INNER")) cost_inner = (float)atof(e);      // experiments only
     float gain = RT_SUB_GAIN;
     if (const char* e = getenv("RT_SUB_GAIN")) gain = (float)atof(e);                  // experiments only
+    int sweep_max = RT_SUB_SWEEP_MAX;
+    if (const char* e = getenv("RT_SUB_SWEEP_MAX")) sweep_max = std::max(2, atoi(e));  // experiments only
     int sub_min_tris = RT_SUB_MIN_TRIS;
     if (const char* e = getenv("RT_SUB_MIN_TRIS")) sub_min_tris = atoi(e);             // tests: sub-trees in small scenes too
     struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
@@ -1331,7 +1333,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         const float pa = half_area(tight);
         if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
             float best = 3e38f;  // expected triangle tests below this node if it is split
-            if (n <= RT_SUB_SWEEP_MAX) {
+            if (n <= sweep_max) {
                 int best_axis = -1, best_k = -1;
                 for (int axis = 0; axis < 3; axis++) {
                     w.sorted.assign(at.begin() + lo, at.begin() + hi);
