@@ -1497,12 +1497,42 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
     n_inner = n_top + n_sub;
+    // Item index of every inner node, the reference's and the sub-trees' alike: by box area, biggest first (ties: the
+    // reference's nodes in their order, then the sub-tree nodes in theirs).  A random ray meets a box in proportion to
+    // its area, and the LDS node cache of the kernels holds the items from the front.
+    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0);
+    {
+        struct Key { float area; int kind, id; };
+        std::vector<Key> keys;
+        keys.reserve((size_t)n_inner);
+        for (int i = 0; i < nn; i++)
+            if (s->nodes[i].child_a != -1) {
+                const float b[6] = {s->nodes[i].bbox_min[0], s->nodes[i].bbox_min[1], s->nodes[i].bbox_min[2],
+                                    s->nodes[i].bbox_max[0], s->nodes[i].bbox_max[1], s->nodes[i].bbox_max[2]};
+                keys.push_back({i == 0 ? 3e38f : half_area(b), 0, i});  // (the root first, whatever its box)
+            }
+        for (int j = 0; j < n_sub; j++) {
+            const SubNode& nd = subs[(size_t)j];
+            float u[6];
+            for (int k = 0; k < 3; k++) {
+                u[k] = std::min(nd.box[0][k], nd.box[1][k]);
+                u[3 + k] = std::max(nd.box[0][3 + k], nd.box[1][3 + k]);
+            }
+            keys.push_back({half_area(u), 1, j});
+        }
+        if (!getenv("RT_ITEMS_BFS"))  // experiments only: the reference's BFS order, then the sub-trees
+            std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.area > b.area; });
+        for (size_t k = 0; k < keys.size(); k++) {
+            if (keys[k].kind == 0) inner_index[(size_t)keys[k].id] = (int)k;
+            else sub_index[(size_t)keys[k].id] = (int)k;
+        }
+    }
     if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     auto entry_of = [&](int node) -> int {
         const rt_bvh_node& n = s->nodes[node];
         if (n.child_a != -1) return inner_index[node];
         if (n.tri_len == 0) return RT_TRAV_EMPTY;
-        if (sub_root[(size_t)node] >= 0) return n_top + sub_root[(size_t)node];
+        if (sub_root[(size_t)node] >= 0) return sub_index[(size_t)sub_root[(size_t)node]];
         return n_inner + n.tri_offs / RT_TRI_FLOATS;
     };
     std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
@@ -1540,12 +1570,12 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     for (int j = 0; j < n_sub; j++) {
         const SubNode& nd = subs[(size_t)j];
-        float* w = &items[((size_t)n_top + j) * 16];
+        float* w = &items[(size_t)sub_index[(size_t)j] * 16];
         const float *A = nd.box[0], *B = nd.box[1];
         w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
         w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
         w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
-        for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? n_top + nd.e[k] : n_inner + ~nd.e[k]);
+        for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? sub_index[(size_t)nd.e[k]] : n_inner + ~nd.e[k]);
         w[14] = i2f(nd.cnt);
         w[15] = i2f(1);
     }
