@@ -7,7 +7,7 @@
 //  * rt_render_paths_kernel (default) -- persistent 1024-thread blocks, one per CU, sharing an LDS copy of the top
 //    of the tree.  The unit of work is one PATH (pixel, sample); a lane is traversing, or waits for a vertex pass,
 //    and every iteration the wave votes and runs ONE kind of step (vertex pass / triangle test / inner-node
-//    visit / whole-wave test of a big leaf) for the lanes that wait for it.  Per-path radiance goes to a buffer,
+//    visit) for the lanes that wait for it.  Per-path radiance goes to a buffer,
 //    rt_sum_samples_kernel adds it per pixel in sample order => bit-reproducible sums, no float atomics.
 //  * rt_render_kernel (RT_F_LOCKSTEP) -- a wave owns an 8x8 tile, lane = pixel, "trace one ray, shade one hit"
 //    in lock step with path regeneration.
@@ -1258,7 +1258,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (max_depth > RT_STACK_ENTRIES)
         return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
-    // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles gets a tree of its own -- median splits
+    // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own -- surface-area or median splits
     //      of the centroids along the widest axis, sub-leaves of at most sub_leaf triangles, padded boxes; the triangles
     //      are reordered inside the leaf only
     int big_leaf = RT_BIG_LEAF;

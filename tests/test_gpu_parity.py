@@ -128,7 +128,7 @@ def test_sah_fast_mode_agrees_with_oracle_and_reference_tree(ob, rt, gpu, name):
 
 def random_scene(rt, seed, n=None, light_frac=None):
     """A random triangle soup with every material type, a texture, importance-sampled lights, clustered so that the
-    BVH gets leaves of all sizes (incl. empty ones and, with a shallow tree, leaves big enough for the whole-wave test)."""
+    BVH gets leaves of all sizes (incl. empty ones and, with a shallow tree, leaves of hundreds of triangles, which get sub-trees)."""
     rng = np.random.default_rng(seed)
     n = int(rng.integers(40, 1500)) if n is None else n
     c = rng.normal(0, 1.5, (n, 1, 3)) + np.array([0, 0, -6.0])

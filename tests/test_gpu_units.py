@@ -470,7 +470,7 @@ def test_full_hd_properties(rt, gpu, scenes):
 
 def test_config4_field_at_full_size(ob, rt, gpu):
     """BASELINE config 4 at its real size: 628 dragons = 9 999 018 triangles in the reference's depth-16 tree (leaves of
-    ~150 triangles, tested by the whole wave in the path kernel), 3840x2160.  Size-independent properties: the path
+    ~150 triangles, each with a sub-tree of its own on the device), 3840x2160.  Size-independent properties: the path
     kernel and the lock-step kernel (which walks the same leaves one triangle per lane-step) give the same image and
     the same counters; an 8-way tile-row gather equals the single image; and on a crop the oracle agrees bit for bit."""
     sc = rt.Scene.synth_field(628, env_path=os.path.join(rt.ASSET_DIR, "cape_hill_1k.hdr"), env_upsample=4)
