@@ -630,3 +630,23 @@ def test_sub_tree_stress_against_the_full_walk(ob, rt, gpu, monkeypatch, seed):
         bad = np.flatnonzero(gp != op)
         assert bad.size == 0, (min_tris, bad[:10], gp[bad[:10]], op[bad[:10]])
         assert np.array_equal(gt, ot) and np.array_equal(gpos, opos), min_tris
+
+
+def test_sub_tree_build_is_the_same_on_any_number_of_host_threads(ob, rt, gpu, monkeypatch):
+    """The sub-trees of a big scene are built on several host threads (leaves are independent); the item stream, and
+    with it every result and counter, must not depend on how many.  Two dragons = 31 844 triangles, > 4096 leaves
+    with a sub-tree."""
+    sc = rt.Scene.synth_field(2)
+    rng = np.random.default_rng(11)
+    org = rng.normal(0, 1, (20000, 3)) * np.array([6, 0.5, 6]) + np.array([0, 3.0, 0])
+    d = rng.normal(0, 1, (20000, 3)) * np.array([1, 0.3, 1]) - np.array([0, 0.6, 0])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    ref = ob.trace_rays(sc, rays, rt.F_BVH, want_counts=True)
+    assert (ref[0] >= 0).sum() > 2000
+    for threads in ("1", "7"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        gpu.upload(sc)
+        got = gpu.trace_rays(rays, rt.F_BVH, want_counts=True)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), threads
