@@ -18,6 +18,7 @@
 //  * raw-sum accumulators + separate resolve kernels (needed for RCCL sum-reduce and progressive batches).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
                                 // in step, and more kinds of step only break that up: Cornell box -10 %),
 #define RT_SUB_GAIN 1.0f        // ... by this factor at least,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
+#define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
 #ifndef RT_PATH_BATCH
@@ -1211,8 +1213,22 @@ int rt_set_stream(rt_context* c, void* hip_stream) {
     return RT_OK;
 }
 
+namespace {
+struct UploadTimer {  // RT_UPLOAD_TIMING=1: wall time of the stages of rt_upload_scene on stderr (experiments only)
+    bool on = getenv("RT_UPLOAD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void stage(const char* name) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rt upload] %-28s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
+
 int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (!c) return RT_ERR_INVALID;
+    UploadTimer timer;
     if (!s) return set_err(c, RT_ERR_INVALID, "null scene");
     if (s->n_tri_floats % RT_TRI_FLOATS) return set_err(c, RT_ERR_INVALID, "n_tri_floats is not a multiple of 25");
     if ((s->n_tri_floats && !s->tris) || (s->n_nodes && !s->nodes) || (s->n_mats && !s->mats) ||
@@ -1258,6 +1274,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     if (max_depth > RT_STACK_ENTRIES)
         return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
+    timer.stage("checks, depths");
     // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own -- surface-area or median splits
     //      of the centroids along the widest axis, sub-leaves of at most sub_leaf triangles, padded boxes; the triangles
     //      are reordered inside the leaf only
@@ -1424,11 +1441,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         // (the traversal stack must have room below this leaf)
         if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
     }
-    int n_workers = 1;
-    if (candidates.size() >= 4096) {
-        n_workers = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        if (const char* e = getenv("RT_HOST_THREADS")) n_workers = std::min(16, std::max(1, atoi(e)));
-    }
+    timer.stage("areas, flags, candidates");
+    int n_workers_max = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("RT_HOST_THREADS")) n_workers_max = std::min(16, std::max(1, atoi(e)));
+    const int n_workers = candidates.size() >= 4096 ? n_workers_max : 1;
     std::vector<SubWork> work((size_t)n_workers);
     {
         auto run = [&](int wi) {
@@ -1450,6 +1466,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         run(0);
         for (auto& t : th) t.join();
     }
+    timer.stage("sub-tree build (threads)");
     std::vector<SubNode> subs;  // the workers' nodes one after the other (contiguous leaf ranges: same order as one thread's)
     int deepest = max_depth;    // of the whole structure: sizes the traversal stack
     for (SubWork& w : work) {
@@ -1461,39 +1478,6 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         }
         for (const auto& r : w.roots) sub_root[(size_t)r.first] = off + r.second;
         deepest = std::max(deepest, w.deepest);
-    }
-    {   // order the sub-tree nodes by level, big boxes first: the node cache in LDS takes the items from the front
-        const size_t ns = subs.size();
-        std::vector<int> level(ns, 0), perm(ns), inv(ns);
-        std::vector<float> area(ns, 0.f);
-        for (size_t j = 0; j < ns; j++) {  // (children come after their parent in a worker's list)
-            const SubNode& nd = subs[j];
-            float u[6];
-            for (int k = 0; k < 3; k++) {
-                u[k] = std::min(nd.box[0][k], nd.box[1][k]);
-                u[3 + k] = std::max(nd.box[0][3 + k], nd.box[1][3 + k]);
-            }
-            area[j] = half_area(u);
-            for (int k = 0; k < 2; k++)
-                if (nd.e[k] >= 0) level[(size_t)nd.e[k]] = level[j] + 1;
-            perm[j] = (int)j;
-        }
-        std::sort(perm.begin(), perm.end(), [&](int a, int b) {
-            if (level[(size_t)a] != level[(size_t)b]) return level[(size_t)a] < level[(size_t)b];
-            if (area[(size_t)a] != area[(size_t)b]) return area[(size_t)a] > area[(size_t)b];
-            return a < b;
-        });
-        for (size_t j = 0; j < ns; j++) inv[(size_t)perm[j]] = (int)j;
-        std::vector<SubNode> ordered(ns);
-        for (size_t j = 0; j < ns; j++) {
-            SubNode nd = subs[(size_t)perm[j]];
-            for (int k = 0; k < 2; k++)
-                if (nd.e[k] >= 0) nd.e[k] = inv[(size_t)nd.e[k]];
-            ordered[j] = nd;
-        }
-        subs.swap(ordered);
-        for (int& r : sub_root)
-            if (r >= 0) r = inv[(size_t)r];
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
     n_inner = n_top + n_sub;
@@ -1520,8 +1504,21 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             }
             keys.push_back({half_area(u), 1, j});
         }
-        if (!getenv("RT_ITEMS_BFS"))  // experiments only: the reference's BFS order, then the sub-trees
-            std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.area > b.area; });
+        // (only the front matters: the RT_ITEM_FRONT biggest, sorted; behind them the reference's BFS order and the
+        // sub-trees' depth-first order stay as they are, which keeps neighbours in the tree close in memory)
+        if (!getenv("RT_ITEMS_BFS")) {  // experiments only: no reordering
+            const size_t front = std::min<size_t>(RT_ITEM_FRONT, keys.size());
+            std::vector<Key> big(keys);
+            auto bigger = [](const Key& a, const Key& b) { return a.area != b.area ? a.area > b.area : (a.kind != b.kind ? a.kind < b.kind : a.id < b.id); };
+            std::nth_element(big.begin(), big.begin() + (std::ptrdiff_t)front, big.end(), bigger);
+            big.resize(front);
+            std::sort(big.begin(), big.end(), bigger);
+            std::vector<char> taken_top((size_t)std::max(nn, 1), 0), taken_sub((size_t)std::max(n_sub, 1), 0);
+            for (const Key& k : big) (k.kind == 0 ? taken_top : taken_sub)[(size_t)k.id] = 1;
+            for (const Key& k : keys)
+                if (!(k.kind == 0 ? taken_top : taken_sub)[(size_t)k.id]) big.push_back(k);
+            keys.swap(big);
+        }
         for (size_t k = 0; k < keys.size(); k++) {
             if (keys[k].kind == 0) inner_index[(size_t)keys[k].id] = (int)k;
             else sub_index[(size_t)keys[k].id] = (int)k;
@@ -1535,24 +1532,32 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         if (sub_root[(size_t)node] >= 0) return sub_index[(size_t)sub_root[(size_t)node]];
         return n_inner + n.tri_offs / RT_TRI_FLOATS;
     };
+    timer.stage("merge, order");
     std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
     std::vector<float> cold((size_t)std::max(ntri, 1) * 16, 0.f);
     std::vector<int> place((size_t)std::max(ntri, 1), 0);  // triangle -> place
-    for (int p = 0; p < ntri; p++) {
-        const int tri = at[(size_t)p];
-        place[(size_t)tri] = p;
-        const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
-        float* h = &items[((size_t)n_inner + p) * 16];
-        h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
-        h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
-        h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
-        h[9] = i2f((int)tflags[(size_t)p]); h[10] = i2f(leaf_end[(size_t)p]); h[11] = i2f(tri);
-    }
-    for (int i = 0; i < ntri; i++) {
-        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
-        float* cd = &cold[(size_t)i * 16];
-        for (int k = 0; k < 15; k++) cd[k] = t[9 + k];
-        cd[15] = i2f(static_cast<int>(t[24]));  // main.cu:353
+    {
+        auto fill = [&](int lo, int hi) {
+            for (int p = lo; p < hi; p++) {
+                const int tri = at[(size_t)p];
+                place[(size_t)tri] = p;
+                const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+                float* h = &items[((size_t)n_inner + p) * 16];
+                h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
+                h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
+                h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
+                h[9] = i2f((int)tflags[(size_t)p]); h[10] = i2f(leaf_end[(size_t)p]); h[11] = i2f(tri);
+                const float* u = tris + (size_t)p * RT_TRI_FLOATS;             // cold data stays in the reference's order
+                float* cd = &cold[(size_t)p * 16];
+                for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
+                cd[15] = i2f(static_cast<int>(u[24]));  // main.cu:353
+            }
+        };
+        const int nw = ntri >= (1 << 20) ? n_workers_max : 1;
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < nw; wi++) th.emplace_back(fill, (int)((long long)ntri * wi / nw), (int)((long long)ntri * (wi + 1) / nw));
+        fill(0, (int)((long long)ntri / nw));
+        for (auto& t : th) t.join();
     }
     for (int i = 0; i < nn; i++) {
         const rt_bvh_node& n = s->nodes[i];
@@ -1580,6 +1585,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         w[15] = i2f(1);
     }
 
+    timer.stage("item stream, cold data");
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
     std::vector<float> mats(std::max<size_t>(s->n_mats, 1) * 12, 0.f);
     for (size_t i = 0; i < s->n_mats; i++) {
@@ -1644,6 +1650,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     const int root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    timer.stage("materials, lights, spheres");
     free_scene(c);
     int rc;
     if ((rc = upload_buf(c, &c->d_place, place.data(), place.size() * 4)) != RT_OK) return rc;
@@ -1677,6 +1684,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         sc.root_min[k] = nn > 0 ? s->nodes[0].bbox_min[k] : 0.f;
         sc.root_max[k] = nn > 0 ? s->nodes[0].bbox_max[k] : 0.f;
     }
+    timer.stage("device allocations, copies");
     c->bvh_depth = deepest;
     c->has_scene = true;
     return RT_OK;
