@@ -232,6 +232,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_LEAF_STEPS
 #define RT_LEAF_STEPS 1   // triangle tests per vote
 #endif
+#ifndef RT_TRACE_STEPS
+#define RT_TRACE_STEPS 4  // traversal steps of the wavefront trace kernel per look at the queue (1 / 2 / 4: 85.2 / 81.4 / 79.6 ms)
+#endif
 #ifndef RT_PATH_BATCH
 #define RT_PATH_BATCH 512
 #endif
@@ -792,7 +795,9 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
             }
         }
         if (!__any(has)) break;  // nothing in flight: the queue is exhausted as well
-        if (has && t.cur != RT_TRAV_DONE) trav_step<STATS, true>(sc, t, stk, cn, n_cached);
+#pragma unroll
+        for (int k = 0; k < RT_TRACE_STEPS; k++)  // (several steps before the next look at the queue)
+            if (has && t.cur != RT_TRAV_DONE) trav_step<STATS, true>(sc, t, stk, cn, n_cached);
         if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
             int tri = t.hitTri;
             f3 hp = tri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
