@@ -226,6 +226,28 @@ int rt_resolve_device(rt_context* ctx, float* dev_out, size_t n_floats, int mode
 int rt_trace_rays(rt_context* ctx, const float* org_dir, size_t n, uint32_t flags,
                   int32_t* prim_id, float* t, float* hit_pos, float* normal3, int32_t* counts);
 
+/* Inspection hook, no device needed: the layout rt_upload_scene copies to the
+ * GPU, built in host memory.  The reference has no counterpart (it uploads
+ * its arrays as they are, main.cu:418-460); this exists so that the item
+ * stream with its leaf sub-trees can be checked on a
+ * machine without a GPU.  items = 16 floats per item (layout in
+ * csrc/rt_device.h): items [0, n_inner) are inner nodes, the triangles
+ * follow; places[id] = place of the reference's triangle id among them.
+ * Pointers stay valid until rt_layout_destroy. */
+typedef struct rt_layout rt_layout;
+typedef struct rt_layout_info {
+    int32_t n_inner;     /* inner items: the reference's nodes and the sub-tree nodes */
+    int32_t n_sub;       /* sub-tree nodes among them */
+    int32_t n_tris;
+    int32_t root_entry;  /* item index of the root, -1 without nodes */
+    int32_t depth;       /* of the whole structure = traversal stack entries */
+    float box_pad;       /* padding of every box the library adds */
+    float cull_far;      /* padded boxes cull only for rays starting within this of the origin */
+} rt_layout_info;
+int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
+int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places);
+void rt_layout_destroy(rt_layout* layout);
+
 /* Test hook: evaluate device-side primitives on n host records.
  * Each op reads `in_stride` floats and writes `out_stride` floats per record
  * (layouts in DESIGN.md "device unit ops"). */

@@ -96,7 +96,7 @@ TRI_FLOATS = 25
 
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback", "rt_readback_rgb8",
               "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
-              "rt_trace_rays", "rt_debug_op", "rt_shade_hits"]
+              "rt_trace_rays", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy"]
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
@@ -171,6 +171,10 @@ def core_lib() -> C.CDLL:
         L.rt_trace_rays.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _ip, _fp, _fp, _fp, _ip]
         L.rt_debug_op.argtypes = [C.c_void_p, C.c_int, _fp, C.c_size_t, _fp, C.POINTER(RenderParams)]
         L.rt_shade_hits.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _fp]
+        L.rt_layout_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.rt_layout_get.argtypes = [C.c_void_p, C.POINTER(LayoutInfo), C.POINTER(_fp), C.POINTER(_ip)]
+        L.rt_layout_destroy.argtypes = [C.c_void_p]
+        L.rt_layout_destroy.restype = None
         _core_lib = L
     return _core_lib
 
@@ -327,6 +331,32 @@ def band_rows_of(params: RenderParams) -> int:
         if (y0 // params.band_rows) % params.band_stride == params.band_index:
             rows += min(params.band_rows, H - y0)
     return rows
+
+
+class LayoutInfo(C.Structure):  # rt_layout_info, include/rt.h
+    _fields_ = [("n_inner", C.c_int32), ("n_sub", C.c_int32), ("n_tris", C.c_int32), ("root_entry", C.c_int32),
+                ("depth", C.c_int32), ("box_pad", C.c_float), ("cull_far", C.c_float)]
+
+
+def device_layout(scene: "Scene"):
+    """The layout rt_upload_scene would copy to the GPU, built on the host (rt_layout_create; no device needed):
+    (LayoutInfo, items [n_items, 16] float32, places [n_tris] int32), copies owned by the caller."""
+    L = core_lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    rc = L.rt_layout_create(C.byref(scene.desc), C.byref(h), err, 256)
+    if rc != 0:
+        raise RuntimeError(f"rt_layout_create: {rc} {err.value.decode()}")
+    try:
+        info = LayoutInfo()
+        items_p, places_p = _fp(), _ip()
+        L.rt_layout_get(h, C.byref(info), C.byref(items_p), C.byref(places_p))
+        n_items = info.n_inner + info.n_tris
+        items = np.ctypeslib.as_array(items_p, shape=(max(n_items, 1), 16))[:n_items].copy()
+        places = np.ctypeslib.as_array(places_p, shape=(max(info.n_tris, 1),))[:info.n_tris].copy()
+    finally:
+        L.rt_layout_destroy(h)
+    return info, items, places
 
 
 # ----------------------------------------------------------------------------- device context

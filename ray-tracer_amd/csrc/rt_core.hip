@@ -1243,18 +1243,27 @@ struct UploadTimer {  // RT_UPLOAD_TIMING=1: wall time of the stages of rt_uploa
 };
 }  // namespace
 
-int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
-    if (!c) return RT_ERR_INVALID;
-    UploadTimer timer;
-    if (!s) return set_err(c, RT_ERR_INVALID, "null scene");
-    if (s->n_tri_floats % RT_TRI_FLOATS) return set_err(c, RT_ERR_INVALID, "n_tri_floats is not a multiple of 25");
+namespace {
+// Everything rt_upload_scene copies to the device, built in host memory (no HIP call): the item stream with the
+// leaf sub-trees, cold triangle data, decoded materials, light records with their group bounds, spheres.
+struct HostLayout {
+    std::vector<float> items, cold, mats, lights, spheres;
+    std::vector<int> place;  // reference triangle id -> place in the item stream
+    int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
+    size_t light_box_off = 0;  // floats into `lights`
+    float scene_scale = 1.f, box_pad = 0.f;
+};
+
+int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, UploadTimer& timer) {
+    auto fail = [&](int code, const std::string& msg) { err = msg; return code; };
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (s->n_tri_floats % RT_TRI_FLOATS) return fail(RT_ERR_INVALID, "n_tri_floats is not a multiple of 25");
     if ((s->n_tri_floats && !s->tris) || (s->n_nodes && !s->nodes) || (s->n_mats && !s->mats) ||
         (s->n_tex_floats && !s->textures) || (s->n_light_tris && !s->light_tris) || s->n_nodes < 0 ||
         s->n_spheres < 0 || s->n_light_tris < 0)
-        return set_err(c, RT_ERR_INVALID, "inconsistent scene arrays");
+        return fail(RT_ERR_INVALID, "inconsistent scene arrays");
     if (s->n_tri_floats / RT_TRI_FLOATS > 0x7fffffffu / RT_TRI_FLOATS)
-        return set_err(c, RT_ERR_INVALID, "too many triangles for int32 float offsets");
-    HIP_TRY(c, hipSetDevice(c->device));
+        return fail(RT_ERR_INVALID, "too many triangles for int32 float offsets");
     const size_t prefix = s->n_spheres > 0 ? 1 + 5 * (size_t)s->n_spheres : 0;
     const float* tris = s->tris + prefix;
     const int ntri = (int)(s->n_tri_floats / RT_TRI_FLOATS);
@@ -1269,15 +1278,15 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         if (n.child_a == -1) {
             if (n.tri_offs < 0 || n.tri_len < 0 || n.tri_offs % RT_TRI_FLOATS || n.tri_len % RT_TRI_FLOATS ||
                 (size_t)n.tri_offs + (size_t)n.tri_len > s->n_tri_floats)
-                return set_err(c, RT_ERR_INVALID, "BVH leaf " + std::to_string(i) + " has a bad triangle range");
+                return fail(RT_ERR_INVALID, "BVH leaf " + std::to_string(i) + " has a bad triangle range");
         } else {
             // children must come after the parent (BFS numbering): guarantees a finite, acyclic walk
             if (n.child_a <= i || n.child_a >= nn || n.child_b <= i || n.child_b >= nn)
-                return set_err(c, RT_ERR_INVALID, "BVH node " + std::to_string(i) + " has bad child indices");
+                return fail(RT_ERR_INVALID, "BVH node " + std::to_string(i) + " has bad child indices");
             inner_index[i] = n_inner++;
         }
     }
-    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
+    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return fail(RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     std::vector<int> depth(nn, 0);
     int max_depth = 0;
     for (int i = 0; i < nn; i++) {
@@ -1289,7 +1298,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         max_depth = std::max(max_depth, depth[i]);
     }
     if (max_depth > RT_STACK_ENTRIES)
-        return set_err(c, RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
+        return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
     timer.stage("checks, depths");
     // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own -- surface-area or median splits
@@ -1427,7 +1436,10 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             if (n <= RT_SUB_LEAF_MAX && !(cost_inner + best < gain * (float)n)) mid = -1;
         }
         if (mid < 0) {
-            if (root) return -1 - 0x40000000;  // not worth a sub-tree: the leaf stays as it is
+            if (root) {  // not worth a sub-tree: the leaf stays as it is, in the reference's order (the sweep has sorted it)
+                std::sort(at.begin() + lo, at.begin() + hi);
+                return -1 - 0x40000000;
+            }
             for (int p = lo; p < hi; p++) tflags[(size_t)p] = (unsigned char)(4 | (p == hi - 1 ? 1 : 0));
             return ~lo;
         }
@@ -1450,7 +1462,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
         for (int k = 0; k < cnt; k++) {
             // a triangle in two leaves would need two "last" flags: the reference builder never does that
-            if (covered[(size_t)first + k]) return set_err(c, RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
+            if (covered[(size_t)first + k]) return fail(RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
             covered[(size_t)first + k] = 1;
             tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
             leaf_end[(size_t)first + k] = first + cnt;
@@ -1541,7 +1553,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
             else sub_index[(size_t)keys[k].id] = (int)k;
         }
     }
-    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return set_err(c, RT_ERR_LIMIT, "scene too large for 32-bit item indices");
+    if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return fail(RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     auto entry_of = [&](int node) -> int {
         const rt_bvh_node& n = s->nodes[node];
         if (n.child_a != -1) return inner_index[node];
@@ -1550,9 +1562,12 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         return n_inner + n.tri_offs / RT_TRI_FLOATS;
     };
     timer.stage("merge, order");
-    std::vector<float> items(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
-    std::vector<float> cold((size_t)std::max(ntri, 1) * 16, 0.f);
-    std::vector<int> place((size_t)std::max(ntri, 1), 0);  // triangle -> place
+    std::vector<float>& items = L.items;
+    std::vector<float>& cold = L.cold;
+    std::vector<int>& place = L.place;
+    items.assign(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
+    cold.assign((size_t)std::max(ntri, 1) * 16, 0.f);
+    place.assign((size_t)std::max(ntri, 1), 0);
     {
         auto fill = [&](int lo, int hi) {
             for (int p = lo; p < hi; p++) {
@@ -1604,7 +1619,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
 
     timer.stage("item stream, cold data");
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
-    std::vector<float> mats(std::max<size_t>(s->n_mats, 1) * 12, 0.f);
+    std::vector<float>& mats = L.mats;
+    mats.assign(std::max<size_t>(s->n_mats, 1) * 12, 0.f);
     for (size_t i = 0; i < s->n_mats; i++) {
         const rt_material& m = s->mats[i];
         float* d = &mats[i * 12];
@@ -1623,7 +1639,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once
     const int n_light_groups = (std::max(s->n_light_tris, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
     const size_t light_box_off = (size_t)std::max(s->n_light_tris, 1) * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records
-    std::vector<float> lights(light_box_off + (size_t)n_light_groups * 8, 0.f);
+    std::vector<float>& lights = L.lights;
+    lights.assign(light_box_off + (size_t)n_light_groups * 8, 0.f);
     for (int g = 0; g < n_light_groups; g++)
         for (int k = 0; k < 3; k++) {
             lights[light_box_off + (size_t)g * 8 + k] = 3e38f;
@@ -1632,7 +1649,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     for (int i = 0; i < s->n_light_tris; i++) {
         const int off = s->light_tris[i];
         if (off < 0 || off % RT_TRI_FLOATS || (size_t)off + RT_TRI_FLOATS > s->n_tri_floats)
-            return set_err(c, RT_ERR_INVALID, "light triangle offset out of range");
+            return fail(RT_ERR_INVALID, "light triangle offset out of range");
         const float* t = tris + off;
         const H3 p1{t[0], t[1], t[2]}, p2{t[3], t[4], t[5]}, p3{t[6], t[7], t[8]};
         const H3 e1 = hsub(p2, p1), e2 = hsub(p3, p1);
@@ -1658,7 +1675,8 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
 
     // ---- spheres
-    std::vector<float> spheres((size_t)std::max(s->n_spheres, 1) * 8, 0.f);
+    std::vector<float>& spheres = L.spheres;
+    spheres.assign((size_t)std::max(s->n_spheres, 1) * 8, 0.f);
     for (int i = 0; i < s->n_spheres; i++) {
         const float* q = s->tris + 1 + 5 * (size_t)i;
         float* d = &spheres[(size_t)i * 8];
@@ -1666,46 +1684,105 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
         d[4] = i2f(static_cast<int>(q[4]));
     }
 
-    const int root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    L.root_entry = nn > 0 ? entry_of(0) : RT_TRAV_DONE;
+    L.n_inner = n_inner;
+    L.n_sub = n_sub;
+    L.n_tris = ntri;
+    L.depth = deepest;
+    L.light_box_off = light_box_off;
+    L.scene_scale = scene_scale;
+    L.box_pad = box_pad;
     timer.stage("materials, lights, spheres");
+    return RT_OK;
+}
+}  // namespace
+
+int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
+    if (!c) return RT_ERR_INVALID;
+    UploadTimer timer;
+    HostLayout L;
+    std::string err;
+    int rc = build_layout(s, L, err, timer);
+    if (rc != RT_OK) return set_err(c, rc, err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int nn = s->n_nodes;
     free_scene(c);
-    int rc;
-    if ((rc = upload_buf(c, &c->d_place, place.data(), place.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_items, items.data(), items.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_cold, cold.data(), cold.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_mats, mats.data(), mats.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_lights, lights.data(), lights.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_spheres, spheres.data(), spheres.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_place, L.place.data(), L.place.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_items, L.items.data(), L.items.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_cold, L.cold.data(), L.cold.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_mats, L.mats.data(), L.mats.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_lights, L.lights.data(), L.lights.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_spheres, L.spheres.data(), L.spheres.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_tex, s->textures, s->n_tex_floats * 4)) != RT_OK) return rc;
 
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
     sc.tri_place = (const int*)c->d_place;
-    sc.n_inner = n_inner;
-    sc.n_sub = n_sub;
-    sc.cull_far = RT_CULL_FAR * scene_scale;
+    sc.n_inner = L.n_inner;
+    sc.n_sub = L.n_sub;
+    sc.cull_far = RT_CULL_FAR * L.scene_scale;
     sc.tri_cold = (const float4*)c->d_cold;
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
-    sc.light_boxes = sc.lights + light_box_off / 4;
+    sc.light_boxes = sc.lights + L.light_box_off / 4;
     sc.spheres = (const float4*)c->d_spheres;
     sc.tex = (const float*)c->d_tex;
     sc.n_tex = (long long)s->n_tex_floats;
-    sc.n_tris = ntri;
+    sc.n_tris = L.n_tris;
     sc.n_mats = (int)s->n_mats;
     sc.n_lights = s->n_light_tris;
     sc.n_spheres = s->n_spheres;
     sc.has_root = nn > 0;
-    sc.root_entry = root_entry;
+    sc.root_entry = L.root_entry;
     for (int k = 0; k < 3; k++) {
         sc.root_min[k] = nn > 0 ? s->nodes[0].bbox_min[k] : 0.f;
         sc.root_max[k] = nn > 0 ? s->nodes[0].bbox_max[k] : 0.f;
     }
     timer.stage("device allocations, copies");
-    c->bvh_depth = deepest;
+    c->bvh_depth = L.depth;
     c->has_scene = true;
     return RT_OK;
 }
+
+// Host-side inspection of the device layout (include/rt.h): no device needed.
+struct rt_layout {
+    HostLayout L;
+};
+
+int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    rt_layout* h = new (std::nothrow) rt_layout();
+    if (!h) return RT_ERR_NOMEM;
+    std::string err;
+    UploadTimer timer;
+    const int rc = build_layout(scene, h->L, err, timer);
+    if (rc != RT_OK) {
+        if (err_buf && err_len) snprintf(err_buf, err_len, "%s", err.c_str());
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return RT_OK;
+}
+
+int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items, const int32_t** places) {
+    if (!h) return RT_ERR_INVALID;
+    if (info) {
+        info->n_inner = h->L.n_inner;
+        info->n_sub = h->L.n_sub;
+        info->n_tris = h->L.n_tris;
+        info->root_entry = h->L.root_entry;
+        info->depth = h->L.depth;
+        info->box_pad = h->L.box_pad;
+        info->cull_far = RT_CULL_FAR * h->L.scene_scale;
+    }
+    if (items) *items = h->L.items.data();
+    if (places) *places = h->L.place.data();
+    return RT_OK;
+}
+
+void rt_layout_destroy(rt_layout* h) { delete h; }
 
 int rt_reset_accum(rt_context* c) {
     if (!c) return RT_ERR_INVALID;

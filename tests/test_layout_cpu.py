@@ -1,0 +1,235 @@
+"""The device layout with its leaf sub-trees, checked WITHOUT a GPU (rt_layout_create, include/rt.h).
+
+Structure: every triangle sits in the item stream exactly once and is reachable exactly once from the root; a
+sub-tree holds the triangles of its reference leaf and nothing else; its padded boxes contain what hangs below
+them; the reference's own nodes keep their boxes and ids.  Behaviour: a float32 re-enactment of the device
+traversal (csrc/rt_device.h: visit_inner, visit_triangle, the tie rule and the pruning slack) on the item stream
+finds the same triangle at the same distance as the oracle's walk over the reference's arrays."""
+import numpy as np
+import pytest
+
+F = np.float32
+EMPTY = 0x3ffffff0
+
+
+def make_scene(rt, seed, n, depth, coincident=False):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-2, 2, (n, 1, 3))
+    v = c + rng.normal(0, rng.choice([0.05, 0.3]), (n, 3, 3))
+    if coincident:                                     # every triangle four times, copies far apart in the array
+        v = np.concatenate([v] * 4)[rng.permutation(4 * n)]
+        n = len(v)
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = v.reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1.0], (n, 3))
+    m = rt.Material(); m.type = 3; m.color = 0x808080; m.image_offset[:] = [-1, -1, -1]
+    return rt.Scene.from_records(t, [m], bvh_max_depth=depth, bvh_min_tris=1), rng
+
+
+def as_int(a):
+    return np.ascontiguousarray(a, np.float32).view(np.int32)
+
+
+def unpack(items, info):
+    inner = items[:info.n_inner]
+    tri = items[info.n_inner:]
+    boxes = np.stack([np.stack([inner[:, 0], inner[:, 1], inner[:, 8], inner[:, 2], inner[:, 3], inner[:, 9]], 1),
+                      np.stack([inner[:, 4], inner[:, 5], inner[:, 10], inner[:, 6], inner[:, 7], inner[:, 11]], 1)], 1)
+    entries = as_int(inner[:, 12:14])
+    third = as_int(inner[:, 14])
+    is_sub = as_int(inner[:, 15]) != 0
+    flags, leaf_end, ids = as_int(tri[:, 9]), as_int(tri[:, 10]), as_int(tri[:, 11])
+    return boxes, entries, third, is_sub, flags, leaf_end, ids
+
+
+@pytest.mark.parametrize("seed,n,depth", [(1, 900, 4), (2, 3000, 16), (3, 400, 1)])
+def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    sc, _ = make_scene(rt, seed, n, depth)
+    info, items, places = rt.device_layout(sc)
+    boxes, entries, third, is_sub, flags, leaf_end, ids = unpack(items, info)
+    nodes, tris = sc.nodes(), sc.tris()
+    assert info.n_tris == n and info.n_sub == is_sub.sum() > 0 and info.root_entry == 0
+    assert sorted(places.tolist()) == list(range(n)) and np.array_equal(ids[places], np.arange(n))
+    v = tris[:, :9].reshape(n, 3, 3)
+    placed = v[ids]                                                    # triangle geometry in item order
+    got = items[info.n_inner:, :9].reshape(n, 3, 3)
+    assert np.array_equal(got[:, 0], placed[:, 0]) and np.array_equal(got[:, 1], placed[:, 1] - placed[:, 0])
+    # reference nodes: boxes and ids as uploaded, children in the reference's A / B order
+    ref_inner = [i for i in range(len(nodes)) if nodes[i]["child_a"] != -1]
+    by_ref = {int(third[k]): k for k in range(info.n_inner) if not is_sub[k]}
+    assert sorted(by_ref) == ref_inner
+    for i in ref_inner:
+        for side, ch in enumerate((nodes[i]["child_a"], nodes[i]["child_b"])):
+            assert np.array_equal(boxes[by_ref[i], side], np.concatenate([nodes[ch]["bbox_min"], nodes[ch]["bbox_max"]]))
+    # one walk over the whole structure: every triangle once, sub-trees confined to their reference leaf
+    seen = np.zeros(n, int)
+    depth_seen = 0
+
+    def leaf_run(first):
+        p, out = first, []
+        while True:
+            out.append(p)
+            if flags[p] & 1:
+                return out
+            p += 1
+
+    def walk(entry, d, in_sub):
+        nonlocal depth_seen
+        depth_seen = max(depth_seen, d)
+        if entry == EMPTY:
+            return []
+        if entry >= info.n_inner:
+            run = leaf_run(entry - info.n_inner)
+            for p in run:
+                seen[p] += 1
+                assert bool(flags[p] & 4) == in_sub
+            return run
+        sub = bool(is_sub[entry])
+        assert sub or not in_sub                                       # no reference node below a sub-tree node
+        below = []
+        for side in range(2):
+            got_below = walk(int(entries[entry, side]), d + 1, sub)
+            if sub:                                                    # the padded box holds everything below it
+                pts = placed[got_below].reshape(-1, 3)
+                assert (pts >= boxes[entry, side, :3]).all() and (pts <= boxes[entry, side, 3:]).all()
+                assert (boxes[entry, side, :3] <= pts.min(0) - 0.5 * info.box_pad).all()
+                assert (boxes[entry, side, 3:] >= pts.max(0) + 0.5 * info.box_pad).all()
+            below += got_below
+        if sub and not in_sub:                                         # root of a sub-tree: one reference leaf, all of it
+            ends = set(leaf_end[below].tolist())
+            assert len(ends) == 1 and len(below) == third[entry] > 0
+            e = ends.pop()
+            assert sorted(ids[below].tolist()) == list(range(e - len(below), e))
+        elif sub:
+            assert third[entry] == 0
+        return below
+
+    walk(info.root_entry, 0, False)
+    assert (seen == 1).all()
+    assert depth_seen <= info.depth <= 24
+    # triangles outside sub-trees stand at their reference place, first / last flags per reference leaf
+    for nd in nodes:
+        if nd["child_a"] == -1 and nd["tri_len"] > 0:
+            first, cnt = nd["tri_offs"] // 25, nd["tri_len"] // 25
+            assert (leaf_end[first:first + cnt] == first + cnt).all()
+            assert sorted(ids[first:first + cnt].tolist()) == list(range(first, first + cnt))
+            if not (flags[first] & 4):
+                assert np.array_equal(ids[first:first + cnt], np.arange(first, first + cnt))
+                assert flags[first] & 2 and flags[first + cnt - 1] & 1
+
+
+def trace_on_items(info, items, o, d):
+    """One ray through the item stream the way csrc/rt_device.h does it, in float32."""
+    o, d = o.astype(F), d.astype(F)
+    with np.errstate(all="ignore"):
+        inv = F(1.0) / d
+        osum = abs(o[0]) + abs(o[1]) + abs(o[2])
+        slack = F(1e-5) * osum * osum if max(abs(o)) <= F(info.cull_far) else F(np.inf)
+        inv_d2 = F(1.00001) / (d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+
+        def box_dist(b):
+            mn, mx = b[:3], b[3:]
+            if (o >= mn).all() and (o <= mx).all():
+                return F(0.0)
+            tmin, tmax = F(0.0), F(1e13)
+            for k in range(3):
+                t1, t2 = (mn[k] - o[k]) * inv[k], (mx[k] - o[k]) * inv[k]
+                tmin = np.fmax(tmin, np.fmin(t1, t2))
+                tmax = np.fmin(tmax, np.fmax(t1, t2))
+            return F(1e13) if tmax < tmin else tmin
+
+        def dot(a, b):
+            return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+        def cross(a, b):
+            return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F)
+
+        min_d2, hit, hit_t = F(1e12), -1, F(0)
+        sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
+        stack, cur, eps = [], info.root_entry, F(1e-9)
+        while True:
+            if cur == EMPTY:
+                pass
+            elif cur < info.n_inner:
+                w = items[cur]
+                bA = np.array([w[0], w[1], w[8], w[2], w[3], w[9]], F)
+                bB = np.array([w[4], w[5], w[10], w[6], w[7], w[11]], F)
+                dA, dB = box_dist(bA), box_dist(bB)
+                dA, dB = dA * dA, dB * dB
+                eA, eB = int(as_int(w[12:13])[0]), int(as_int(w[13:14])[0])
+                lim = sub_lim if as_int(w[15:16])[0] != 0 else min_d2
+                near, far, d_near, d_far = (eA, eB, dA, dB) if dA < dB else (eB, eA, dB, dA)
+                if d_far < lim:
+                    stack.append(far)
+                if d_near < lim:
+                    cur = near
+                    continue
+            else:
+                w = items[cur]
+                v0, e1, e2 = w[0:3], w[3:6], w[6:9]
+                p = cross(d, e2)
+                det = dot(e1, p)
+                if not (det > -eps and det < eps):
+                    inv_det = F(1.0) / det
+                    s = o - v0
+                    u = inv_det * dot(s, p)
+                    if not (u < 0 or u > 1):
+                        q = cross(s, e1)
+                        v = inv_det * dot(d, q)
+                        if not (v < 0 or u + v > 1):
+                            t = inv_det * dot(e2, q)
+                            if t > eps:
+                                pos = o + d * t
+                                r = pos - o
+                                nd = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]
+                                tie = False
+                                if nd == min_d2 and hit >= 0:
+                                    held = items[info.n_inner + hit]
+                                    tie = as_int(held[10:11])[0] == as_int(w[10:11])[0] and as_int(w[11:12])[0] < as_int(held[11:12])[0]
+                                if nd < min_d2 or tie:
+                                    min_d2, hit, hit_t = nd, cur - info.n_inner, t
+                                    sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
+                if not (as_int(w[9:10])[0] & 1):
+                    cur += 1
+                    continue
+            if not stack:
+                break
+            cur = stack.pop()
+        if hit < 0:
+            return -1, F(-1)
+        r = (o + d * hit_t) - o
+        return int(as_int(items[info.n_inner + hit][11:12])[0]), np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], dtype=F)
+
+
+@pytest.mark.parametrize("seed,n,depth,coincident", [(11, 700, 3, False), (12, 1500, 16, False), (13, 150, 2, True)])
+def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, seed, n, depth, coincident):
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    sc, rng = make_scene(rt, seed, n, depth, coincident)
+    info, items, _ = rt.device_layout(sc)
+    assert info.n_sub > 0
+    k = 250
+    v = sc.tris()[:, :9].reshape(-1, 3, 3).astype(np.float64)
+    target = np.einsum("kj,kjc->kc", rng.dirichlet([1, 1, 1], k), v[rng.integers(0, len(v), k)])
+    org = np.concatenate([rng.normal(0, 4, (k // 2, 3)),                           # outside, inside,
+                          np.einsum("kj,kjc->kc", rng.dirichlet([1, 1, 1], k - k // 2), v[rng.integers(0, len(v), k - k // 2)])])
+    d = target - org + 1e-9                                                        # ... and from points ON triangles
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::5] = np.eye(3)[rng.integers(0, 3, len(d[::5]))]                            # some along the axes
+    d[1::7] *= 2.5                                                                 # some not unit vectors
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    prim, t = ob.trace_rays(sc, rays, rt.F_BVH)[:2]
+    assert (prim >= 0).sum() > k // 3
+    for i in range(k):
+        p, tt = trace_on_items(info, items, rays[i, :3], rays[i, 3:])
+        assert p == prim[i] and (p < 0 or tt == t[i]), (i, p, prim[i], tt, t[i])
+
+
+def test_layout_errors_are_reported(rt):
+    sc, _ = make_scene(rt, 5, 40, 3)
+    sc.desc.n_tri_floats -= 1
+    try:
+        with pytest.raises(RuntimeError, match="multiple of 25"):
+            rt.device_layout(sc)
+    finally:
+        sc.desc.n_tri_floats += 1
