@@ -225,6 +225,33 @@ def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, 
         assert p == prim[i] and (p < 0 or tt == t[i]), (i, p, prim[i], tt, t[i])
 
 
+@pytest.mark.parametrize("scale,dist", [(1e-3, 1.0), (1.0, 3e4), (1e3, 10.0), (30.0, 2e4)])
+def test_float32_walk_at_extreme_scales(ob, rt, monkeypatch, scale, dist):
+    """Tiny and huge scenes, origins far outside the range in which the padded boxes may cull (rt_layout_info.cull_far)."""
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    rng = np.random.default_rng(int(scale * 3 + dist) % 997)
+    n = 500
+    v = (rng.normal(0, 1.0, (n, 1, 3)) + rng.normal(0, 0.1, (n, 3, 3))) * scale
+    t = np.zeros((n, 25), np.float32)
+    t[:, 0:9] = v.reshape(n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1.0], (n, 3))
+    m = rt.Material(); m.type = 3; m.color = 0x808080; m.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(t, [m], bvh_max_depth=2, bvh_min_tris=1)
+    info, items, _ = rt.device_layout(sc)
+    assert info.n_sub > 0
+    k = 160
+    d0 = rng.normal(0, 1, (k, 3)); d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    org = d0 * dist * scale + rng.normal(0, 0.3 * scale, (k, 3))
+    d = rng.normal(0, 0.6 * scale, (k, 3)) - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    prim, tt = ob.trace_rays(sc, rays, rt.F_BVH)[:2]
+    assert (prim >= 0).sum() > k // 10
+    for i in range(k):
+        p, td = trace_on_items(info, items, rays[i, :3], rays[i, 3:])
+        assert p == prim[i] and (p < 0 or td == tt[i]), (i, p, prim[i])
+
+
 def test_layout_errors_are_reported(rt):
     sc, _ = make_scene(rt, 5, 40, 3)
     sc.desc.n_tri_floats -= 1
