@@ -1301,9 +1301,9 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
     timer.stage("checks, depths");
-    // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own -- surface-area or median splits
-    //      of the centroids along the widest axis, sub-leaves of at most sub_leaf triangles, padded boxes; the triangles
-    //      are reordered inside the leaf only
+    // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own where the
+    //      surface-area estimate says it pays (build_sub below): padded boxes, the triangles reordered inside the
+    //      leaf only, built on the host threads
     int big_leaf = RT_BIG_LEAF;
     float cost_inner = RT_SUB_COST_INNER;
     if (const char* e = getenv("RT_BIG_LEAF")) big_leaf = std::max(2, atoi(e));       // experiments only
