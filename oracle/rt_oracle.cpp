@@ -496,6 +496,19 @@ Vec3 rand_sphere_vec(Rng& rng) {  // :130-140
     return Vec3(x, y, z);
 }
 
+// Vec3::randSphere, vec3.h:133-142: as above except that theta's pi is the double literal 3.14159 (vec3.h:136), so
+// the product is formed in double and rounded to float.  Called by checkScatteredVolume only (main.cu:137).
+Vec3 vec3_rand_sphere(Rng& rng) {
+    float r1 = rng.uniform();
+    float r2 = rng.uniform();
+    float theta = r1 * 2.0f * 3.14159;
+    float phi = pm::acos(2.0f * r2 - 1.0f);
+    float x = pm::sin(phi) * pm::cos(theta);
+    float y = pm::sin(phi) * pm::sin(theta);
+    float z = pm::cos(phi);
+    return Vec3(x, y, z);
+}
+
 Vec3 rand_cosine_hemisphere(const Vec3& normal, Rng& rng) {  // :152-161
     Vec3 s = rand_sphere_vec(rng);
     float cos_theta = s.dot(normal);
@@ -758,7 +771,7 @@ bool check_scattered_volume(Ray& ray, const Vec3& hitPos, Rng& rng, uint32_t bou
     ray.position.x += step.x;
     ray.position.y += step.y;
     ray.position.z += step.z;
-    ray.direction = rand_sphere_vec(rng);
+    ray.direction = vec3_rand_sphere(rng);  // Vec3::randSphere (double pi), main.cu:137
     ray.diffuseMultiplier = ray.diffuseMultiplier * ray.volumeColor;
     return true;
 }
@@ -822,10 +835,14 @@ Vec3 render_pixel(const Scene& sc, const rt_render_params& p, int x, int y, Coun
                     rng.seek(RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)j);
                     // Reference indexes materials[hitSphereIndex + 4] (main.cu:341), which is
                     // the wrong array; the material id stored in the sphere record is used.
+                    // An id outside the material array (the reference would read out of bounds) shades like a
+                    // material without a texture: "the color of error" of Sphere::getTextureColor, sphere.h:64.
                     int mi = static_cast<int>(sc.spheres[hitSphereIndex + 4]);
-                    if (mi < 0 || (size_t)mi >= sc.nMats) mi = 0;
+                    rt_material m;
+                    if (mi >= 0 && (size_t)mi < sc.nMats) m = sc.mats[mi];
+                    else { memset(&m, 0, sizeof(m)); m.image_offset[0] = m.image_offset[1] = m.image_offset[2] = -1; }
                     c.hits++;
-                    hit_sphere(sc, sc.mats[mi], ray, sphereHitNormal, sphereHitPos, rng, c);
+                    hit_sphere(sc, m, ray, sphereHitNormal, sphereHitPos, rng, c);
                     continue;
                 }
             }

@@ -23,7 +23,7 @@ static int usage() {
 
 int main(int argc, char** argv) {
     std::string scene, asset_root, out = "output.png", env;
-    int spp = -1, bounces = 6, W = 0, H = 0, device = 0;
+    int spp = -1, bounces = -1, W = 0, H = 0, device = 0;
     unsigned seed = 37811;
     bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false;
     for (int i = 1; i < argc; i++) {
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
         else return usage();
     }
     if (scene.empty()) return usage();
+    if (bounces < 0) bounces = raymarch ? 100 : 6;  // RAY_MARCHING_MAX_STEPS config.h:15 / MAX_BOUNCES config.h:3
 
     rt_host_scene* hs = nullptr;
     if (rt_scene_load(scene.c_str(), asset_root.empty() ? nullptr : asset_root.c_str(), env.empty() ? nullptr : env.c_str(),

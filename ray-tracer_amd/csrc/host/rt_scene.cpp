@@ -778,20 +778,23 @@ int build_bvh_sah(float* tris, size_t n_floats, int max_depth, int leaf_tris, st
 
 // ------------------------------------------------------------------ scene DSL
 
-// SceneParser::nth_word, sceneParser.cpp:307-326 (split on single spaces).
-std::string nth_word(const std::string& line, int n) {
-    size_t start = 0;
-    size_t end = line.find(' ');
-    int count = 0;
-    while (end != std::string::npos) {
-        if (count == n) return line.substr(start, end - start);
-        start = end + 1;
-        end = line.find(' ', start);
-        count++;
+// A scene line cut into words once (the DSL of sceneParser.cpp:22-171 separates words by ONE space, so two spaces
+// in a row hold an empty word between them, as the reference's per-call word lookup sees it too).
+struct Words {
+    std::vector<std::string> w;
+    explicit Words(const std::string& line) {
+        std::string cur;
+        for (char ch : line) {
+            if (ch == ' ') { w.push_back(cur); cur.clear(); }
+            else cur.push_back(ch);
+        }
+        w.push_back(cur);
     }
-    if (count == n) return line.substr(start);
-    return "";
-}
+    const std::string& operator[](size_t n) const {
+        static const std::string none;
+        return n < w.size() ? w[n] : none;
+    }
+};
 
 struct ATexture { std::string name, path; bool loaded = false; int offset = 0, w = 0, h = 0; };
 struct AModel { std::string name, path; };
@@ -853,10 +856,8 @@ struct Parser {
         cam.env_width = 0; cam.env_height = 0;  // (reference: 4096x2048 even without an env map; forced to 0 = none)
     }
 
-    bool vec3(const std::string& line, V3& v) {
-        return stof_ok(nth_word(line, 1), v.x) && stof_ok(nth_word(line, 2), v.y) && stof_ok(nth_word(line, 3), v.z);
-    }
-    bool vec3(const std::string& line, float* v) {
+    bool vec3(const Words& line, V3& v) { return stof_ok(line[1], v.x) && stof_ok(line[2], v.y) && stof_ok(line[3], v.z); }
+    bool vec3(const Words& line, float* v) {
         V3 t;
         if (!vec3(line, t)) return false;
         v[0] = t.x; v[1] = t.y; v[2] = t.z;
@@ -879,42 +880,43 @@ struct Parser {
             if (!line.empty() && line.back() == '\r') line.pop_back();
             if (line.empty()) { scope = GLOBAL; continue; }
             if (line[0] == '#') continue;
-            const std::string w0 = nth_word(line, 0);
+            const Words words(line);
+            const std::string& w0 = words[0];
             bool ok = true;
             switch (scope) {
                 case IMAGE:
-                    if (w0 == "PATH") textures.back().path = nth_word(line, 1);
+                    if (w0 == "PATH") textures.back().path = words[1];
                     else return bad("unknown IMAGE definition command: " + w0);
                     continue;
                 case MODEL:
-                    if (w0 == "PATH") models.back().path = nth_word(line, 1);
+                    if (w0 == "PATH") models.back().path = words[1];
                     else return bad("unknown MODEL definition command: " + w0);
                     continue;
                 case MATERIAL: {
                     AMaterial& m = materials.back();
-                    if (w0 == "TYPE") ok = stoi_ok(nth_word(line, 1), m.type);
-                    else if (w0 == "COLOR") ok = vec3(line, m.color);
-                    else if (w0 == "P1") ok = stof_ok(nth_word(line, 1), m.p1);
-                    else if (w0 == "P2") ok = stof_ok(nth_word(line, 1), m.p2);
-                    else if (w0 == "P3") ok = stof_ok(nth_word(line, 1), m.p3);
+                    if (w0 == "TYPE") ok = stoi_ok(words[1], m.type);
+                    else if (w0 == "COLOR") ok = vec3(words, m.color);
+                    else if (w0 == "P1") ok = stof_ok(words[1], m.p1);
+                    else if (w0 == "P2") ok = stof_ok(words[1], m.p2);
+                    else if (w0 == "P3") ok = stof_ok(words[1], m.p3);
                     else if (w0 == "TEXTURE") {
                         if (m.images.size() >= 3) return bad("too many textures for material: " + m.name);
-                        m.images.push_back(nth_word(line, 1));
+                        m.images.push_back(words[1]);
                     } else return bad("unknown MATERIAL definition command: " + w0);
                     if (!ok) return bad("bad number");
                     continue;
                 }
                 case OBJECT:
-                    if (w0 == "MODEL") objects.back().model = nth_word(line, 1);
-                    else if (w0 == "MATERIAL") objects.back().material = nth_word(line, 1);
+                    if (w0 == "MODEL") objects.back().model = words[1];
+                    else if (w0 == "MATERIAL") objects.back().material = words[1];
                     else return bad("unknown OBJECT definition command: " + w0);
                     continue;
                 case INSTANCE: {
                     AInstance& in = instances.back();
-                    if (w0 == "OBJECT") in.object = nth_word(line, 1);
-                    else if (w0 == "POSITION") ok = vec3(line, in.pos);
-                    else if (w0 == "SCALE") ok = stof_ok(nth_word(line, 1), in.scale);
-                    else if (w0 == "ROTATION") ok = vec3(line, in.rot);
+                    if (w0 == "OBJECT") in.object = words[1];
+                    else if (w0 == "POSITION") ok = vec3(words, in.pos);
+                    else if (w0 == "SCALE") ok = stof_ok(words[1], in.scale);
+                    else if (w0 == "ROTATION") ok = vec3(words, in.rot);
                     else if (w0 == "IMPORTANCE_SAMPLE") in.importance = true;
                     else return bad("unknown OBJECT INSTANCE definition command: " + w0);
                     if (!ok) return bad("bad number");
@@ -923,31 +925,31 @@ struct Parser {
                 case SPHERE: {
                     if (!enable_spheres) continue;  // sceneParser.cpp:285
                     ASphere& s = spheres.back();
-                    if (w0 == "POSITION") ok = vec3(line, s.pos);
-                    else if (w0 == "RADIUS") ok = stof_ok(nth_word(line, 1), s.radius);
-                    else if (w0 == "MATERIAL") s.material = nth_word(line, 1);
+                    if (w0 == "POSITION") ok = vec3(words, s.pos);
+                    else if (w0 == "RADIUS") ok = stof_ok(words[1], s.radius);
+                    else if (w0 == "MATERIAL") s.material = words[1];
                     else return bad("unknown SPHERE definition command: " + w0);
                     if (!ok) return bad("bad number");
                     continue;
                 }
                 case GLOBAL: break;
             }
-            if (w0 == "SET_OUTPUT_WIDTH") ok = stoi_ok(nth_word(line, 1), cam.width);
-            else if (w0 == "SET_OUTPUT_HEIGHT") ok = stoi_ok(nth_word(line, 1), cam.height);
-            else if (w0 == "SET_NUM_SAMPLES") ok = stoi_ok(nth_word(line, 1), cam.num_samples);
-            else if (w0 == "SET_CAM_POS") ok = vec3(line, cam.pos);
-            else if (w0 == "SET_CAM_ROTATION") ok = vec3(line, cam.rot);
-            else if (w0 == "SET_CAM_VEL") ok = vec3(line, cam.vel);
-            else if (w0 == "SET_CAM_ANGULAR_VEL") ok = vec3(line, cam.ang_vel);
-            else if (w0 == "SET_FOCAL_LENGTH") ok = stof_ok(nth_word(line, 1), cam.focal_length);
-            else if (w0 == "SET_APERTURE_RADIUS") ok = stof_ok(nth_word(line, 1), cam.aperture);
-            else if (w0 == "SET_FOCUS_DISTANCE") ok = stof_ok(nth_word(line, 1), cam.focus_distance);
-            else if (w0 == "SET_BACKGROUND") background = nth_word(line, 1);
+            if (w0 == "SET_OUTPUT_WIDTH") ok = stoi_ok(words[1], cam.width);
+            else if (w0 == "SET_OUTPUT_HEIGHT") ok = stoi_ok(words[1], cam.height);
+            else if (w0 == "SET_NUM_SAMPLES") ok = stoi_ok(words[1], cam.num_samples);
+            else if (w0 == "SET_CAM_POS") ok = vec3(words, cam.pos);
+            else if (w0 == "SET_CAM_ROTATION") ok = vec3(words, cam.rot);
+            else if (w0 == "SET_CAM_VEL") ok = vec3(words, cam.vel);
+            else if (w0 == "SET_CAM_ANGULAR_VEL") ok = vec3(words, cam.ang_vel);
+            else if (w0 == "SET_FOCAL_LENGTH") ok = stof_ok(words[1], cam.focal_length);
+            else if (w0 == "SET_APERTURE_RADIUS") ok = stof_ok(words[1], cam.aperture);
+            else if (w0 == "SET_FOCUS_DISTANCE") ok = stof_ok(words[1], cam.focus_distance);
+            else if (w0 == "SET_BACKGROUND") background = words[1];
             else if (w0 == "ADD_OBJECT") { scope = INSTANCE; instances.emplace_back(); }
-            else if (w0 == "DEF_IMAGE") { scope = IMAGE; textures.emplace_back(); textures.back().name = nth_word(line, 1); }
-            else if (w0 == "DEF_MODEL") { scope = MODEL; models.emplace_back(); models.back().name = nth_word(line, 1); }
-            else if (w0 == "DEF_MATERIAL") { scope = MATERIAL; materials.emplace_back(); materials.back().name = nth_word(line, 1); }
-            else if (w0 == "DEF_OBJ") { scope = OBJECT; objects.emplace_back(); objects.back().name = nth_word(line, 1); }
+            else if (w0 == "DEF_IMAGE") { scope = IMAGE; textures.emplace_back(); textures.back().name = words[1]; }
+            else if (w0 == "DEF_MODEL") { scope = MODEL; models.emplace_back(); models.back().name = words[1]; }
+            else if (w0 == "DEF_MATERIAL") { scope = MATERIAL; materials.emplace_back(); materials.back().name = words[1]; }
+            else if (w0 == "DEF_OBJ") { scope = OBJECT; objects.emplace_back(); objects.back().name = words[1]; }
             else if (w0 == "ADD_SPHERE") { scope = SPHERE; spheres.emplace_back(); }
             else return bad("unknown command: " + w0);
             if (!ok) return bad("bad number");

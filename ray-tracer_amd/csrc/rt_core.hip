@@ -1054,6 +1054,8 @@ struct rt_context {
     size_t samples_floats = 0;
     std::vector<hipEvent_t> ev_pool;
     unsigned int* h_pinned = nullptr;
+    void* d_scratch = nullptr;   // grow-only device scratch of the readbacks and test hooks (no allocation per call)
+    size_t scratch_bytes = 0;
 };
 
 namespace {
@@ -1106,6 +1108,20 @@ inline H3 hnormalize_keep(H3 a) {  // vec3.h:97-105
 float* accum_ptr(rt_context* c) { return c->d_accum_ext ? c->d_accum_ext : c->d_accum_own; }
 size_t accum_cap(rt_context* c) { return c->d_accum_ext ? c->accum_ext_floats : c->accum_own_floats; }
 
+// Grow-only scratch of the context: a progressive-preview loop (render, read back, render, ...) allocates once.
+int ensure_scratch(rt_context* c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return RT_OK;
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    if (hipMalloc(&c->d_scratch, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return set_err(c, RT_ERR_NOMEM, "device scratch allocation failed");
+    }
+    c->scratch_bytes = bytes;
+    return RT_OK;
+}
+
 int rows_of(const rt_render_params* p) {
     const int H = p->cam.height;
     if (p->band_stride <= 1 || p->band_rows <= 0) return H;
@@ -1126,6 +1142,9 @@ int make_params(rt_context* c, const rt_render_params* p, Params& P) {
         return set_err(c, RT_ERR_INVALID, "volume scattering / ray marching run on the default fused kernel only");
     if (p->band_stride > 1 && (p->band_rows <= 0 || p->band_index < 0 || p->band_index >= p->band_stride))
         return set_err(c, RT_ERR_INVALID, "bad band partition");
+    // the wavefront pipeline keeps (sample << 8 | bounce) in one word of the slot state (rt_logic_kernel)
+    if ((p->flags & RT_F_WAVEFRONT) && (p->max_bounces > 255 || p->sample_count >= (1 << 23)))
+        return set_err(c, RT_ERR_LIMIT, "wavefront pipeline: at most 255 bounces and 2^23 - 1 samples per call");
     memset(&P, 0, sizeof(P));
     P.width = p->cam.width;
     P.height = p->cam.height;
@@ -1214,6 +1233,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_samples) (void)hipFree(c->d_samples);
     if (c->d_wf) (void)hipFree(c->d_wf);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -2128,17 +2148,16 @@ int rt_readback_rgb8(rt_context* c, unsigned char* rgb8, size_t n_bytes) {
     if (n == 0 || !accum_ptr(c)) return set_err(c, RT_ERR_INVALID, "nothing rendered yet");
     if (n_bytes != n) return set_err(c, RT_ERR_INVALID, "n_bytes does not match rows*width*3 of the last render");
     HIP_TRY(c, hipSetDevice(c->device));
-    unsigned char* tmp = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&tmp, n));
+    int rc = ensure_scratch(c, n);
+    if (rc != RT_OK) return rc;
+    unsigned char* tmp = (unsigned char*)c->d_scratch;
     const size_t npix = n / 3;
     const float samples = static_cast<float>(c->samples_done > 0 ? c->samples_done : 1);
     hipLaunchKernelGGL(rt_resolve_rgb8_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, accum_ptr(c), tmp, npix, samples);
-    int rc = RT_OK;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(rgb8, tmp, n, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = set_err(c, RT_ERR_DEVICE, std::string("8-bit readback: ") + hipGetErrorString(e));
-    (void)hipFree(tmp);
     return rc;
 }
 
@@ -2153,14 +2172,14 @@ int rt_readback(rt_context* c, float* rgb, size_t n_floats, int mode) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return RT_OK;
     }
-    float* tmp = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&tmp, n * sizeof(float)));
-    int rc = rt_resolve_device(c, tmp, n, mode);
+    int rc = ensure_scratch(c, n * sizeof(float));
+    if (rc != RT_OK) return rc;
+    float* tmp = (float*)c->d_scratch;
+    rc = rt_resolve_device(c, tmp, n, mode);
     if (rc == RT_OK) {
         hipError_t e = hipMemcpy(rgb, tmp, n * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_err(c, RT_ERR_DEVICE, std::string("readback copy: ") + hipGetErrorString(e));
     }
-    (void)hipFree(tmp);
     return rc;
 }
 
@@ -2185,17 +2204,21 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     if (!org_dir) return set_err(c, RT_ERR_INVALID, "null rays");
     if (n > 0x7fffffffu / 8) return set_err(c, RT_ERR_INVALID, "too many rays in one call");
     HIP_TRY(c, hipSetDevice(c->device));
-    DevTmp tmp;
-    float* d_rays = (float*)tmp.get(n * 6 * 4);
-    float4* d_q = (float4*)tmp.get(n * 32);
-    float4* d_hits = (float4*)tmp.get(n * 16);
-    int* d_prim = (int*)tmp.get(n * 4);
-    float* d_t = (float*)tmp.get(n * 4);
-    float* d_pos = (float*)tmp.get(n * 12);
-    float* d_nrm = (float*)tmp.get(n * 12);
-    int* d_cnt = (int*)tmp.get(n * 12);
-    if (!d_rays || !d_q || !d_hits || !d_prim || !d_t || !d_pos || !d_nrm || !d_cnt)
-        return set_err(c, RT_ERR_NOMEM, "device scratch allocation failed");
+    // one block of the context's grow-only scratch, cut into 256-byte aligned pieces
+    const size_t sizes[8] = {n * 24, n * 32, n * 16, n * 4, n * 4, n * 12, n * 12, n * 12};
+    size_t offs[8], total = 0;
+    for (int i = 0; i < 8; i++) { offs[i] = total; total += (sizes[i] + 255) & ~(size_t)255; }
+    int rc = ensure_scratch(c, total);
+    if (rc != RT_OK) return rc;
+    char* base = (char*)c->d_scratch;
+    float* d_rays = (float*)(base + offs[0]);
+    float4* d_q = (float4*)(base + offs[1]);
+    float4* d_hits = (float4*)(base + offs[2]);
+    int* d_prim = (int*)(base + offs[3]);
+    float* d_t = (float*)(base + offs[4]);
+    float* d_pos = (float*)(base + offs[5]);
+    float* d_nrm = (float*)(base + offs[6]);
+    int* d_cnt = (int*)(base + offs[7]);
     HIP_TRY(c, hipMemcpyAsync(d_rays, org_dir, n * 24, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(rt_fill_queue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_rays, n, d_q);
     unsigned int* d_n = c->d_tile_counter + 8;  // [8] = ray count, [9] = cursor
@@ -2203,7 +2226,7 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     HIP_TRY(c, hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_cnt, 0, n * 12, c->stream));
     const TraceCfg tc = trace_cfg(c);
-    int rc = set_trace_lds(c, tc);
+    rc = set_trace_lds(c, tc);
     if (rc != RT_OK) return rc;
     // the same persistent kernel the renderer uses (with refill), restricted to closest hit (+ spheres if asked)
     hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,

@@ -708,9 +708,20 @@ __device__ __forceinline__ f3 fetch_texel(const Scene& sc, long long i) {
     return mk(sc.tex[i], sc.tex[i + 1], sc.tex[i + 2]);
 }
 
-// Material::randSphereVec, material.h:130-140 (same body: Vec3::randSphere, Sphere::randSphereVec)
+// Material::randSphereVec, material.h:130-140 (same body: Sphere::randSphereVec, sphere.h:48-58)
 __device__ __forceinline__ f3 rand_sphere_vec(float r1, float r2) {
     const float theta = r1 * 2.0f * 3.14159f;
+    const float phi = pm::acos(2.0f * r2 - 1.0f);
+    float sp, cp, st, ct;
+    pm::sincos(phi, &sp, &cp);
+    pm::sincos(theta, &st, &ct);
+    return mk(sp * ct, sp * st, cp);
+}
+
+// Vec3::randSphere, vec3.h:133-142: the same but for theta, whose pi is the DOUBLE literal 3.14159 (vec3.h:136):
+// (r1 * 2.0f) is promoted, multiplied in double and rounded to float.  Only checkScatteredVolume calls it (main.cu:137).
+__device__ __forceinline__ f3 rand_sphere_vec3(float r1, float r2) {
+    const float theta = (float)((double)(r1 * 2.0f) * 3.14159);
     const float phi = pm::acos(2.0f * r2 - 1.0f);
     float sp, cp, st, ct;
     pm::sincos(phi, &sp, &cp);
@@ -1063,7 +1074,7 @@ __device__ __forceinline__ bool check_scattered_volume(PathState& ray, f3 hitPos
     const float dist_to_target = sqrtf(len2(hitPos - ray.o));
     if (travel_dist > dist_to_target) return false;  // no scattering
     ray.o = ray.o + ray.d * travel_dist;
-    ray.d = rand_sphere_vec(u01(V.y), u01(V.z));
+    ray.d = rand_sphere_vec3(u01(V.y), u01(V.z));  // Vec3::randSphere, not Material::randSphereVec
     ray.thr = ray.thr * ray.volColor;
     return true;
 }

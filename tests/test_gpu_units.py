@@ -237,6 +237,36 @@ def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
 
 
 @pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
+def test_sphere_material_out_of_range_is_the_error_colour(ob, rt, gpu, tmp_path, mode):
+    """A sphere record whose material id lies outside the material array (the reference would read out of bounds,
+    main.cu:341) shades like a material without a texture -- Sphere::getTextureColor's "color of error"
+    (sphere.h:64) -- in the oracle and in every schedule of the HIP path alike."""
+    txt = ("SET_OUTPUT_WIDTH 40\nSET_OUTPUT_HEIGHT 32\nSET_FOCAL_LENGTH 0.5\n\nDEF_IMAGE earth\nPATH earth.ppm\n\n"
+           "DEF_MODEL m\nPATH plane.obj\n\nDEF_MATERIAL a\nTYPE 3\nCOLOR 0.5 0.5 0.5\nTEXTURE earth\n\nDEF_OBJ o\nMODEL m\nMATERIAL a\n\n"
+           "ADD_OBJECT\nOBJECT o\nPOSITION 0 -1 -4\nSCALE 4.0\n\n"
+           "ADD_SPHERE\nPOSITION 0 0 -3\nRADIUS 0.6\nMATERIAL a\n\nADD_SPHERE\nPOSITION -1.2 0.2 -4\nRADIUS 0.7\nMATERIAL a\n")
+    f = tmp_path / "s.txt"
+    f.write_text(txt)
+    sc = rt.Scene.load(str(f), enable_spheres=True)
+    pre = np.ctypeslib.as_array(sc.desc.tris, shape=(sc.prefix,))
+    imgs = []
+    for mat in (0.0001, 99.0001, -3.0):
+        pre[5] = mat                              # sphere 0: [N, (x, y, z, r, mat) ...]
+        gpu.upload(sc)
+        p = rt.default_params(sc.camera, spp=3, flags=rt.F_DEFAULT | rt.F_SPHERES | rt.F_STATS | rt.MODE_FLAGS[mode])
+        gpu.reset()
+        st = gpu.render(p)
+        o, ost = ob.render(sc, p, n_threads=4)
+        img = gpu.readback()
+        assert np.array_equal(img, o), mat
+        assert (st.rays, st.hits, st.texel_fetches) == (ost.rays, ost.hits, ost.texel_fetches)
+        imgs.append(img)
+    assert np.array_equal(imgs[1], imgs[2]) and not np.array_equal(imgs[0], imgs[1])
+    centre = imgs[1][16, 20]                      # the untextured sphere fills the image centre: magenta paths only
+    assert centre[1] == 0.0 and centre[0] > 0.0 and centre[2] > 0.0
+
+
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
 def test_motion_blur_and_ragged_image_sizes(ob, rt, gpu, scenes, mode):
     sc = scenes("scene.txt")
     gpu.upload(sc)
@@ -386,6 +416,13 @@ def test_error_codes_instead_of_exit(rt, scenes):
         assert L.rt_render(h, C.byref(bad), None) == -1 and b"fused kernel only" in L.rt_last_error(h)
         bad = rt.RenderParams.from_buffer_copy(p); bad.band_rows, bad.band_stride, bad.band_index = 4, 2, 2
         assert L.rt_render(h, C.byref(bad), None) == -1
+        # the wavefront pipeline packs (sample << 8 | bounce) into one word: larger counts are refused, not mis-rendered
+        bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_WAVEFRONT; bad.max_bounces = 256
+        assert L.rt_render(h, C.byref(bad), None) == -4 and b"255 bounces" in L.rt_last_error(h)
+        bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_WAVEFRONT; bad.sample_count = 1 << 23
+        assert L.rt_render(h, C.byref(bad), None) == -4
+        ok = rt.RenderParams.from_buffer_copy(p); ok.flags |= rt.F_WAVEFRONT; ok.max_bounces = 255
+        assert L.rt_render(h, C.byref(ok), None) == 0
         bad = rt.RenderParams.from_buffer_copy(p); bad.cam.env_width, bad.cam.env_height = 4096, 2048   # larger than the pool
         assert L.rt_render(h, C.byref(bad), None) == -1
         out = np.zeros(8 * 8 * 3, np.float32)
