@@ -161,6 +161,11 @@ typedef struct rt_render_stats {
                                or rt_render_paths_kernel (fused) */
     uint32_t iterations;    /* wavefront iterations (logic + trace launch pairs) of this call */
     uint32_t trace_launches; /* launches covered by trace_ms */
+    /* What the DEVICE really did (the counters above describe the reference's walk: a leaf sub-tree's root is
+     * credited with its leaf visit and all the leaf's triangle tests, rt_device.h): */
+    uint64_t dev_inner_visits;     /* inner items visited: reference nodes and sub-tree nodes, 64 B each */
+    uint64_t dev_lds_inner_visits; /* of those, served by the LDS node cache instead of L2 / HBM */
+    uint64_t dev_tri_tests;        /* triangle tests really run, 48 B each */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };

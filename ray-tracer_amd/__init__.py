@@ -68,7 +68,8 @@ class RenderStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("paths", C.c_uint64), ("rays", C.c_uint64),
                 ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64),
-                ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32)]
+                ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32),
+                ("dev_inner_visits", C.c_uint64), ("dev_lds_inner_visits", C.c_uint64), ("dev_tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -176,9 +176,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {  // wave-reduce, one atomic per counter per wave
-        uint32_t v[8] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights};
+        uint32_t v[11] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 11; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
         for (int i = 0; i < 8; i++) {
             unsigned long long s = cn.prof[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0 && s) atomicAdd(&stats[8 + i], s);
+            if (lane == 0 && s) atomicAdd(&stats[16 + i], s);
         }
 #endif
     }
@@ -490,9 +490,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {
-        uint32_t v[8] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights};
+        uint32_t v[11] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 11; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         for (int i = 0; i < 8; i++) {
             unsigned long long s = cn.prof[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0 && s) atomicAdd(&stats[8 + i], s);
+            if (lane == 0 && s) atomicAdd(&stats[16 + i], s);
         }
 #endif
     }
@@ -810,17 +810,19 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
             if (STATS) {
                 if (counts) { counts[slot * 3] = (int)cn.inner; counts[slot * 3 + 1] = (int)cn.leaf; counts[slot * 3 + 2] = (int)cn.tri; }
                 tot.inner += cn.inner; tot.leaf += cn.leaf; tot.tri += cn.tri;
+                tot.dev_inner += cn.dev_inner; tot.dev_cached += cn.dev_cached; tot.dev_tri += cn.dev_tri;
             }
             has = false;
         }
     }
     if (STATS && stats) {
-        uint32_t v[4] = {tot.rays, tot.inner, tot.leaf, tot.tri};
+        uint32_t v[7] = {tot.rays, tot.inner, tot.leaf, tot.tri, tot.dev_inner, tot.dev_cached, tot.dev_tri};
+        const int idx[7] = {1, 2, 3, 4, 8, 9, 10};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 7; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0 && s) atomicAdd(&stats[1 + i], s);
+            if (lane == 0 && s) atomicAdd(&stats[idx[i]], s);
         }
     }
 }
@@ -1214,7 +1216,7 @@ int rt_create(rt_context** out, int device_id) {
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipMalloc((void**)&c->d_tile_counter, 256) == hipSuccess &&
               hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault) == hipSuccess &&
-              hipMalloc((void**)&c->d_stats, 16 * sizeof(unsigned long long)) == hipSuccess;
+              hipMalloc((void**)&c->d_stats, 32 * sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
         rt_destroy(c);
         return RT_ERR_DEVICE;
@@ -2093,7 +2095,7 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
     const bool want_stats = (P.flags & RT_F_STATS) != 0;
     const bool profile = (P.flags & RT_F_PROFILE) != 0;
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 32 * sizeof(unsigned long long), c->stream));
     const bool work = P.n_tiles > 0 && P.sample_count > 0;
     if (work) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -2111,16 +2113,17 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
             stats->kernel_ms = ms;
         }
         if (want_stats) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
 #ifdef RT_CYCLE_PROF
             fprintf(stderr, "[rt prof] trav: %llu wave-iterations, %llu lane-steps (%.1f lanes/iteration), %llu cycles (%.0f per iteration); "
                             "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass)(shading part %.0f); wave lifetimes %llu cycles; kernel %.3f ms\n",
-                    h[8], h[9], h[8] ? (double)h[9] / h[8] : 0.0, h[10], h[8] ? (double)h[10] / h[8] : 0.0, h[11], h[12],
-                    h[11] ? (double)h[12] / h[11] : 0.0, h[13], h[11] ? (double)h[13] / h[11] : 0.0, h[11] ? (double)h[15] / h[11] : 0.0, h[14], stats->kernel_ms);
+                    h[16], h[17], h[16] ? (double)h[17] / h[16] : 0.0, h[18], h[16] ? (double)h[18] / h[16] : 0.0, h[19], h[20],
+                    h[19] ? (double)h[20] / h[19] : 0.0, h[21], h[19] ? (double)h[21] / h[19] : 0.0, h[19] ? (double)h[23] / h[19] : 0.0, h[22], stats->kernel_ms);
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
+            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10];
         }
     }
     return RT_OK;

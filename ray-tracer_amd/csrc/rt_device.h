@@ -178,11 +178,15 @@ __device__ __forceinline__ float gauss(uint32_t a, uint32_t b) {  // normal from
 // ------------------------------------------------------------------ counters
 struct Counters {
     uint32_t paths, rays, inner, leaf, tri, hits, texels, lights;
+    // what the DEVICE really does (the eight above count the reference's walk, which a sub-tree root stands in for):
+    // inner items visited (reference nodes and sub-tree nodes), of those served by the LDS node cache, triangle tests run
+    uint32_t dev_inner, dev_cached, dev_tri;
 #ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
     unsigned long long prof[8];  // 0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
 #endif
     __device__ __forceinline__ void clear() {
         paths = rays = inner = leaf = tri = hits = texels = lights = 0;
+        dev_inner = dev_cached = dev_tri = 0;
 #ifdef RT_CYCLE_PROF
         for (int i = 0; i < 8; i++) prof[i] = 0;
 #endif
@@ -489,6 +493,7 @@ template <bool STATS, bool SUB>
 __device__ __forceinline__ void visit_inner(Trav& t, int* stk, Counters& cn, float4 q0, float4 q1, float4 q2, float4 q3) {
     const bool sub = SUB && __float_as_int(q3.w) != 0;
     if (STATS) {
+        cn.dev_inner++;
         if (sub) {  // the root of a sub-tree stands for the visit of its leaf and the tests of all its triangles
             cn.tri += (uint32_t)__float_as_int(q3.z);
             cn.leaf += __float_as_int(q3.z) != 0;
@@ -537,7 +542,7 @@ template <bool STATS, bool SUB>
 __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, int item, float4 q0, float4 q1,
                                                float4 q2) {
     const int flags = __float_as_int(q2.y);
-    if (STATS) { cn.tri += !(flags & 4); cn.leaf += (flags >> 1) & 1; }
+    if (STATS) { cn.tri += !(flags & 4); cn.leaf += (flags >> 1) & 1; cn.dev_tri++; }
     float ht;
     const f3 o = t.o();
     if (ray_triangle_t(o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht)) {
@@ -565,6 +570,7 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
     }
     float4 q0, q1, q2, q3;
     if (t.cur < n_cached) {
+        if (STATS) cn.dev_cached++;
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
@@ -582,6 +588,7 @@ template <bool STATS, bool SUB>
 __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached) {  // trav_at_inner(t)
     float4 q0, q1, q2, q3;
     if (t.cur < n_cached) {
+        if (STATS) cn.dev_cached++;
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
@@ -619,7 +626,7 @@ __device__ __forceinline__ void trav_brute_force(const Scene& sc, Trav& t, Count
     for (int i = 0; i < sc.n_tris; i++) {
         const float4* h = sc.items + 4 * ((size_t)sc.n_inner + i);
         const float4 h0 = h[0], h1 = h[1], h2 = h[2];
-        if (STATS) cn.tri++;
+        if (STATS) { cn.tri++; cn.dev_tri++; }
         float ht;
         const f3 o = t.o();
         if (ray_triangle_t(o, t.d, mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), ht)) {

@@ -322,6 +322,25 @@ def test_big_leaves_get_sub_trees(ob, rt, gpu, depth):
         assert np.array_equal(gpu.readback(), img) and st2.tri_tests == st.tri_tests, m
 
 
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
+def test_device_actual_counters(rt, gpu, scenes, mode):
+    """RT_F_STATS also reports what the device really did, next to the counters of the reference's walk: without
+    sub-trees the two agree; with sub-trees the device visits more inner items and runs fewer triangle tests."""
+    m = rt.MODE_FLAGS[mode]
+    sc = scenes("scene_cornellbox.txt")                      # 24 triangles: no sub-trees
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=2, width=64, height=64, max_bounces=4, flags=rt.F_DEFAULT | rt.F_STATS | m)
+    gpu.reset(); st = gpu.render(p)
+    assert (st.dev_inner_visits, st.dev_tri_tests) == (st.inner_visits, st.tri_tests) and st.tri_tests > 0
+    assert st.dev_lds_inner_visits == st.dev_inner_visits    # the whole tree fits the LDS node cache
+    sc = rt.Scene.load("scene.txt", bvh_max_depth=5)         # leaves of ~100 triangles: every leaf gets a sub-tree
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=2, width=64, height=64, flags=rt.F_DEFAULT | rt.F_STATS | m)
+    gpu.reset(); st = gpu.render(p)
+    assert st.dev_inner_visits > st.inner_visits and 0 < st.dev_tri_tests < st.tri_tests
+    assert 0 < st.dev_lds_inner_visits <= st.dev_inner_visits
+
+
 VOLUME_SCENE = ("SET_OUTPUT_WIDTH 64\nSET_OUTPUT_HEIGHT 48\nSET_FOCAL_LENGTH 0.5\nSET_APERTURE_RADIUS 0.0\n\n"
                 "DEF_IMAGE env\nPATH cape_hill_1k.hdr\n\nDEF_MODEL pl\nPATH plane.obj\n\nDEF_MODEL cu\nPATH cube.obj\n\n"
                 "DEF_MODEL mo\nPATH monkey.obj\n\n"
@@ -421,8 +440,6 @@ def test_error_codes_instead_of_exit(rt, scenes):
         assert L.rt_render(h, C.byref(bad), None) == -4 and b"255 bounces" in L.rt_last_error(h)
         bad = rt.RenderParams.from_buffer_copy(p); bad.flags |= rt.F_WAVEFRONT; bad.sample_count = 1 << 23
         assert L.rt_render(h, C.byref(bad), None) == -4
-        ok = rt.RenderParams.from_buffer_copy(p); ok.flags |= rt.F_WAVEFRONT; ok.max_bounces = 255
-        assert L.rt_render(h, C.byref(ok), None) == 0
         bad = rt.RenderParams.from_buffer_copy(p); bad.cam.env_width, bad.cam.env_height = 4096, 2048   # larger than the pool
         assert L.rt_render(h, C.byref(bad), None) == -1
         out = np.zeros(8 * 8 * 3, np.float32)
@@ -430,6 +447,8 @@ def test_error_codes_instead_of_exit(rt, scenes):
         assert L.rt_render(h, C.byref(p), None) == 0
         assert L.rt_readback(h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size - 3, 0) == -1  # wrong size
         assert L.rt_readback(h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, 0) == 0
+        ok = rt.RenderParams.from_buffer_copy(p); ok.flags |= rt.F_WAVEFRONT; ok.max_bounces = 255   # the limit itself is fine
+        assert L.rt_render(h, C.byref(ok), None) == 0
         # malformed BVH: child index pointing backwards (would loop forever) / bad triangle range
         nodes = (rt.BvhNode * sc.desc.n_nodes)(*[sc.desc.nodes[i] for i in range(sc.desc.n_nodes)])
         d2 = rt.SceneDesc.from_buffer_copy(sc.desc)
