@@ -231,6 +231,18 @@ int rt_resolve_device(rt_context* ctx, float* dev_out, size_t n_floats, int mode
 int rt_trace_rays(rt_context* ctx, const float* org_dir, size_t n, uint32_t flags,
                   int32_t* prim_id, float* t, float* hit_pos, float* normal3, int32_t* counts);
 
+/* rt_trace_rays for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (its main() allocates freely,
+ * src/main.cu:418-460): it is for code under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc.  The call makes no hipMalloc / hipFree and no host copy: rays in and results out are DEVICE pointers
+ * (org_dir n x 6 floats; prim_id, t, hit_pos n x 3, normal3 n x 3 as in rt_trace_rays, each may be NULL), and the
+ * ray queue, hit records and control words of the trace kernel live in a file-scope device array of the library
+ * (12 MiB per GPU, held until the process ends).  n > RT_TRACE_NOALLOC_MAX_RAYS is refused with RT_ERR_LIMIT.
+ * Work is enqueued on the context's stream (rt_set_stream); sync != 0 waits for it before returning.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two contexts or two streams) race. */
+#define RT_TRACE_NOALLOC_MAX_RAYS (1 << 18)
+int rt_trace_rays_noalloc(rt_context* ctx, const float* dev_org_dir, size_t n, uint32_t flags, int32_t* dev_prim_id,
+                          float* dev_t, float* dev_hit_pos, float* dev_normal3, int sync);
+
 /* Inspection hook, no device needed: the layout rt_upload_scene copies to the
  * GPU, built in host memory.  The reference has no counterpart (it uploads
  * its arrays as they are, main.cu:418-460); this exists so that the item

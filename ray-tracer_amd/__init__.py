@@ -97,7 +97,7 @@ TRI_FLOATS = 25
 
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback", "rt_readback_rgb8",
               "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
-              "rt_trace_rays", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy"]
+              "rt_trace_rays", "rt_trace_rays_noalloc", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy"]
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
@@ -170,6 +170,8 @@ def core_lib() -> C.CDLL:
         L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.rt_trace_rays.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _ip, _fp, _fp, _fp, _ip]
+        L.rt_trace_rays_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int]
         L.rt_debug_op.argtypes = [C.c_void_p, C.c_int, _fp, C.c_size_t, _fp, C.POINTER(RenderParams)]
         L.rt_shade_hits.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _fp]
         L.rt_layout_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]

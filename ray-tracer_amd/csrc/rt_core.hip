@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -853,6 +854,17 @@ __global__ void rt_fill_queue_kernel(const float* __restrict__ rays, size_t n, f
     rayq[2 * i + 1] = make_float4(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5], 0.f);
 }
 
+// The same for rt_trace_rays_noalloc: the rays are in device memory already, and the kernel also sets the two words the
+// trace kernel starts from (ctl[0] = ray count, ctl[1] = cursor of the chunks handed out), so that no copy from host
+// memory is needed.  ctl is the head of the static scratch array, which keeps the last call's contents.
+__global__ void rt_fill_queue_ctl_kernel(const float* __restrict__ rays, size_t n, float4* __restrict__ rayq, unsigned int* __restrict__ ctl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { ctl[0] = (unsigned int)n; ctl[1] = 0u; }
+    if (i >= n) return;
+    rayq[2 * i] = make_float4(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2], __int_as_float((int)i));
+    rayq[2 * i + 1] = make_float4(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5], 0.f);
+}
+
 // avg + tone map of main.cu:392-406 applied to raw sums
 __global__ void rt_resolve_kernel(const float* __restrict__ accum, float* __restrict__ out, size_t n_pixels,
                                   float samples, int mode) {
@@ -1020,6 +1032,35 @@ __global__ void rt_debug_kernel(int op, const float* __restrict__ in, size_t n, 
 
 // =============================================================================== host side
 
+// Scratch of rt_trace_rays_noalloc (include/rt.h): control words, ray queue and hit records of one call, in a
+// file-scope device array, so that the entry point needs no allocation.  Every GPU the library runs on holds its own
+// copy (12 MiB) until the process ends.  In host code the array's NAME is only a stand-in for hipGetSymbolAddress:
+// rt_create looks the address up once per device (noalloc_scratch_of) and everything below uses that pointer.
+#define RT_NOALLOC_MAX_RAYS (1 << 18)
+#define RT_NOALLOC_CTL_BYTES 256
+#define RT_NOALLOC_BYTES (RT_NOALLOC_CTL_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * (32 + 16))  // queue entry 32 B + hit record 16 B per ray
+static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
+
+#define RT_MAX_DEVICES 64
+static void* g_noalloc_ptr[RT_MAX_DEVICES];  // device address of rt_noalloc_scratch on each device, set once by rt_create
+static std::mutex g_noalloc_mutex;
+
+// Device `dev` must be current.  Returns hipSuccess and the device's own address of the array.
+static hipError_t noalloc_scratch_of(int dev, void** out) {
+    *out = nullptr;
+    if (dev < 0 || dev >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt_noalloc_scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return hipSuccess;
+}
+
 struct rt_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -1056,6 +1097,7 @@ struct rt_context {
     size_t samples_floats = 0;
     std::vector<hipEvent_t> ev_pool;
     unsigned int* h_pinned = nullptr;
+    void* noalloc_scratch = nullptr;  // this device's address of rt_noalloc_scratch
     void* d_scratch = nullptr;   // grow-only device scratch of the readbacks and test hooks (no allocation per call)
     size_t scratch_bytes = 0;
 };
@@ -1212,7 +1254,8 @@ int rt_create(rt_context** out, int device_id) {
     c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
+    bool ok = noalloc_scratch_of(device_id, &c->noalloc_scratch) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipMalloc((void**)&c->d_tile_counter, 256) == hipSuccess &&
               hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault) == hipSuccess &&
@@ -2243,6 +2286,37 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     if (normal3) HIP_TRY(c, hipMemcpyAsync(normal3, d_nrm, n * 12, hipMemcpyDeviceToHost, c->stream));
     if (counts) HIP_TRY(c, hipMemcpyAsync(counts, d_cnt, n * 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+// rt_trace_rays for callers that cannot allocate (include/rt.h): rays and results in DEVICE memory, queue / hit records /
+// control words in the static scratch array of this device, no hipMalloc, hipFree or host copy.  Same kernels as rt_trace_rays.
+int rt_trace_rays_noalloc(rt_context* c, const float* dev_org_dir, size_t n, uint32_t flags, int32_t* dev_prim_id, float* dev_t,
+                          float* dev_hit_pos, float* dev_normal3, int sync) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) return set_err(c, RT_ERR_NO_SCENE, "rt_trace_rays_noalloc before rt_upload_scene");
+    if (n > (size_t)RT_NOALLOC_MAX_RAYS)
+        return set_err(c, RT_ERR_LIMIT, "rt_trace_rays_noalloc: at most " + std::to_string(RT_NOALLOC_MAX_RAYS) + " rays per call (static scratch)");
+    if (n == 0) return RT_OK;
+    if (!dev_org_dir) return set_err(c, RT_ERR_INVALID, "null rays");
+    if (!c->noalloc_scratch) return set_err(c, RT_ERR_DEVICE, "static scratch address unknown");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned char* base = (unsigned char*)c->noalloc_scratch;   // the pointer from hipGetSymbolAddress, never the array's name
+    unsigned int* ctl = (unsigned int*)base;
+    float4* d_q = (float4*)(base + RT_NOALLOC_CTL_BYTES);
+    float4* d_hits = (float4*)(base + RT_NOALLOC_CTL_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * 32);
+    const TraceCfg tc = trace_cfg(c);
+    int rc = set_trace_lds(c, tc);  // (a function attribute, set once per context: no allocation)
+    if (rc != RT_OK) return rc;
+    // the queue and the control words are rewritten for every call (the array keeps the previous call's contents);
+    // hit records are written for every ray of this call before rt_hitinfo_kernel reads them
+    hipLaunchKernelGGL(rt_fill_queue_ctl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_org_dir, n, d_q, ctl);
+    hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, ctl, ctl + 1, d_hits,
+                       flags, (int*)nullptr, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
+    hipLaunchKernelGGL(rt_hitinfo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, dev_org_dir, d_hits, n, dev_prim_id,
+                       dev_t, dev_hit_pos, dev_normal3);
+    HIP_TRY(c, hipGetLastError());
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
