@@ -1,30 +1,57 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the path-tracing core (BASELINE.json metric: Mrays/s incl. bounces).
 
-Workload at N=1 (BASELINE.json configs[1]): scenes/scene.txt (the reference's scene.txt: monkey + two spheres +
-plane, 2 889 triangles, cape_hill_1k.hdr environment) at 1920x1080, 64 spp, MAX_BOUNCES 6.  One "step" = one
-full pass of the hot path over that batch: reset accumulators, render 1920x1080x64 paths with rt_render
-(closest-hit traversal + shading + accumulation), and -- for N > 1 -- combine accumulators over RCCL.
+One "step" = one full pass of the hot path over one batch: reset accumulators, render with rt_render (closest-hit
+traversal + shading + accumulation) and -- for N > 1 -- combine the accumulators over RCCL.
 
-N > 1 (one process per GPU, launched by torch.distributed.run):
-  --partition samples (default): rank r renders sample slice [r*spp, (r+1)*spp) of every pixel, then one RCCL
-      sum-reduce of the float accumulators to rank 0 (BASELINE config 5 pattern).  Per-GPU work is fixed -> "weak".
-  --partition rows: image rows interleaved in bands of 16 over the ranks, RCCL gather to rank 0
-      (BASELINE config 4 pattern).  Total work fixed -> "strong".
+Workloads (`--config`, BASELINE.json configs; explicit flags override a preset):
+  c2   (default) scenes/scene.txt 1920x1080, 64 spp, 6 bounces            -- the configuration the metric is quoted on
+  c3   scene2.txt 1920x1080, 256 spp             c3is  scene2_is.txt (960 importance-sampled light triangles), 256 spp
+  c4   synthetic 10M-triangle field, 3840x2160, 128 spp, image rows over the ranks, RCCL gather      (strong scaling)
+  c5   Cornell box 1920x1080, 4096 spp IN TOTAL, sample slices of 4096/N spp per rank, RCCL sum-reduce (strong scaling)
+c2 / c3 with N > 1 keep `--spp` samples PER RANK (sample slices, weak scaling).
 
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the environment; started plainly as
+`python bench.py --gpus N`, bench.py starts the N ranks itself (a torch.distributed.run child process, before
+anything in this process touches the GPU) and exits with its code.
+
+Prints ONE JSON line on rank 0.  `roofline` names the limit that binds:
+  valu  useful vector lane-operations (SQ_THREAD_CYCLES_VALU, active lanes only) per second against the chip's issue
+        peak for plain f32 vector instructions (tools/micro/valu_peak.hip)           = issue_util x lane_util
+  hbm   measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) per second against 8 TB/s
+The counters are a STORED measurement (profiles/r*_pmc_<workload>.json, written by tools/round_profile.sh with
+rocprofv3 in separate --pmc passes); counts per launch are deterministic for a workload and a build, the launch
+duration is measured live with HIP events.  `algorithmic_GBps` keeps SURVEY 8(d)'s figure (bytes of the REFERENCE's
+walk per second): it is served by the LDS node cache and L2 and may exceed the HBM peak -- it is not a roofline.
 """
 import argparse
-import ctypes
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+CLOCK_GHZ = 2.4              # peak engine clock
+N_SIMD = 256 * 4
+# cycles one SIMD needs per plain f32 wave64 instruction at its best: 2 (SIMD-32; MI355X_MICROARCH.md).  Measured with
+# >= 2 waves per SIMD: 2.2-2.4 (profiles/r02_valu_peak.txt, tools/micro/valu_peak.hip); the nominal 2 is the peak used.
+VALU_CYCLES_PER_WAVE_INST = 2.0
+VALU_PEAK_TLANEOPS = N_SIMD * 64 / VALU_CYCLES_PER_WAVE_INST * CLOCK_GHZ * 1e9 / 1e12
+
+PRESETS = {
+    "c2": dict(scene="scene.txt", width=1920, height=1080, spp=64, partition="samples", total_spp=False),
+    "c3": dict(scene="scene2.txt", width=1920, height=1080, spp=256, partition="samples", total_spp=False),
+    "c3is": dict(scene="scene2_is.txt", width=1920, height=1080, spp=256, partition="samples", total_spp=False),
+    "c4": dict(synth_instances=628, width=3840, height=2160, spp=128, partition="rows", total_spp=False),
+    "c5": dict(scene="scene_cornellbox.txt", width=1920, height=1080, spp=4096, partition="samples", total_spp=True),
+}
 
 
 def algorithmic_bytes(st, n_pixels):
@@ -35,24 +62,84 @@ def algorithmic_bytes(st, n_pixels):
             12 * st.texel_fetches + 36 * st.light_tests + 12 * n_pixels)
 
 
-def main():
+def source_sha():
+    """Hash of the HIP sources the render kernels are built from: a stored counter file is stale once it changes."""
+    h = hashlib.sha256()
+    for f in ("rt_core.hip", "rt_device.h", "rt_pmath.h"):
+        with open(os.path.join(ROOT, "ray-tracer_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def workload_key(args):
+    base = f"synth{args.synth_instances}" if args.synth_instances > 0 else os.path.splitext(os.path.basename(args.scene))[0]
+    return f"{base}_{args.width}x{args.height}_{args.spp}spp_{args.bounces}b_{args.mode}_{args.bvh}"
+
+
+def stored_pmc(key):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{key}.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        d["file"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except Exception:
+        return None
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="scene.txt")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="c2")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel (per rank, except --config c5 / --total-spp: in total)")
+    ap.add_argument("--total-spp", action="store_true", default=None, help="--spp is the job's total: each rank renders spp/N")
     ap.add_argument("--bounces", type=int, default=6)
-    ap.add_argument("--partition", choices=["samples", "rows"], default="samples")
+    ap.add_argument("--partition", choices=["samples", "rows"], default=None)
     ap.add_argument("--mode", choices=["wavefront", "megakernel", "lockstep"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
-    ap.add_argument("--synth-instances", type=int, default=0, help="use the synthetic instanced field instead of --scene")
+    ap.add_argument("--synth-instances", type=int, default=None, help="use the synthetic instanced field instead of --scene")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="sah = the NON-PARITY fast mode (binned-SAH tree, depth <= 24, leaves <= 2), reported separately")
     args = ap.parse_args()
+    pre = PRESETS[args.config]
+    if args.scene is not None and args.synth_instances is None:
+        args.synth_instances = 0
+    for k, v in pre.items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+    if args.scene is None:
+        args.scene = "scene.txt"
+    if args.synth_instances is None:
+        args.synth_instances = 0
+    return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child torch.distributed.run (this process has
+    not touched the GPU and does not), hand its output through and exit with its code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     # torch first: its bundled HIP runtime has the same SONAME as /opt/rocm's, so librt_amd.so binds to
     # the one already loaded and torch tensors / RCCL and our kernels share one runtime.
@@ -67,14 +154,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a scaling run must have one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL sees {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     if args.synth_instances > 0:
         scene = rt.Scene.synth_field(args.synth_instances, env_path=os.path.join(rt.ASSET_DIR, "cape_hill_1k.hdr"),
@@ -86,7 +175,14 @@ def main():
     if args.bvh == "sah":
         scene.rebuild_bvh("sah")
         workload += f" [non-parity SAH tree, {scene.desc.n_nodes} nodes]"
-    W, H, spp = args.width, args.height, args.spp
+    W, H = args.width, args.height
+    if args.total_spp and args.partition == "samples":
+        if args.spp % world:
+            raise SystemExit(f"--spp {args.spp} in total does not divide over {world} ranks")
+        spp = args.spp // world           # c5: 4096 spp in total, 4096 / N per rank
+    else:
+        spp = args.spp                    # samples: per rank (weak); rows: every rank renders all samples of its rows
+    strong = world > 1 and (args.partition == "rows" or args.total_spp)
 
     r = rt.Renderer(local_rank)
     r.upload(scene)
@@ -154,8 +250,9 @@ def main():
         total_rays, total_paths = float(st_counts.rays), float(st_counts.paths)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        mrays = total_rays / (elapsed / args.steps) / 1e6
+        step_s = elapsed / max(args.steps, 1)
+        ms_per_step = step_s * 1e3
+        mrays = total_rays / step_s / 1e6
         k_ms = float(np.mean(kernel_ms))          # all kernels of one frame (HIP events on the render stream)
         abytes = algorithmic_bytes(st_counts, rows * W)
         if args.mode == "wavefront" and st_prof.trace_launches > 0:
@@ -172,14 +269,59 @@ def main():
             dom_ms, launches = float(np.mean(dom_ms_steps)), dom_launches
         else:
             dom_kernel, dom_bytes, dom_ms, launches = "rt_render_kernel", abytes, k_ms, 1
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.synth_instances == 0 and args.scene == "scene.txt" and args.bvh == "reference" and (W, H, spp) == (1920, 1080, 64):
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        launch_s = dom_ms * 1e-3 / launches       # average duration of one launch of the dominant kernel, measured live
+        roof = {"kernel": dom_kernel, "launches_per_step": launches, "avg_launch_ms": round(dom_ms / launches, 4),
+                "frame_kernels_ms": round(k_ms, 3)}
+        # what the device requests per launch, by the level that serves it (RT_F_STATS device counters): inner items
+        # from the LDS node cache, the other inner items and every triangle test from L1/L2 (HBM only on a miss)
+        lds_b = 64 * st_counts.dev_lds_inner_visits / launches
+        l2_b = (64 * (st_counts.dev_inner_visits - st_counts.dev_lds_inner_visits) + 48 * st_counts.dev_tri_tests +
+                (64 + 48 + 48) * st_counts.hits + 12 * st_counts.texel_fetches + 64 * st_counts.light_tests) / launches
+        roof["device_requests"] = {
+            "inner_items_visited": int(st_counts.dev_inner_visits), "of_those_from_lds": int(st_counts.dev_lds_inner_visits),
+            "triangle_tests_run": int(st_counts.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
+            "lds_GBps": round(lds_b / launch_s / 1e9, 1), "lds_peak_GBps": 150000.0,
+            "l2_GBps": round(l2_b / launch_s / 1e9, 1), "l2_peak_GBps": 34500.0}
+        roof["algorithmic_bytes_per_launch"] = int(dom_bytes / launches)
+        roof["algorithmic_GBps"] = round(dom_bytes / launches / launch_s / 1e9, 1)   # the reference's walk; NOT a roofline (cache resident)
+        roof["bytes_per_ray"] = round(abytes / max(st_counts.rays, 1), 1)
+        pmc = stored_pmc(workload_key(args)) if world == 1 else None
+        fracs = {}
+        if pmc:
+            c = pmc["per_launch"]
+            stale = pmc.get("source_sha") != source_sha()
+            roof["pmc"] = {"file": pmc["file"], "git_head": pmc.get("git_head"), "stored_kernel_ms": pmc.get("kernel_trace_avg_ms"),
+                           "stale": stale, "note": "counts per launch stored by tools/round_profile.sh; duration measured in this run"}
+            if "SQ_INSTS_VALU" in c and "SQ_THREAD_CYCLES_VALU" in c:
+                insts, lane_ops = c["SQ_INSTS_VALU"], c["SQ_THREAD_CYCLES_VALU"]
+                issue_util = insts * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_GHZ * 1e9 * launch_s)
+                lane_util = lane_ops / (64.0 * insts)
+                roof["valu"] = {"wave_insts_per_launch": insts, "lane_ops_per_launch": lane_ops,
+                                "issue_util": round(issue_util, 4), "lane_util": round(lane_util, 4),
+                                "achieved_Tlaneops": round(lane_ops / launch_s / 1e12, 3), "peak_Tlaneops": round(VALU_PEAK_TLANEOPS, 2),
+                                "frac": round(issue_util * lane_util, 4)}
+                fracs["valu"] = issue_util * lane_util
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0   # KB; gfx950: FETCH_SIZE counts half (MI355X_MICROARCH.md)
+                roof["hbm"] = {"measured_bytes_per_launch": int(hbm_bytes), "measured_GBps": round(hbm_bytes / launch_s / 1e9, 1),
+                               "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)}
+                fracs["hbm"] = hbm_bytes / launch_s / 1e9 / HBM_PEAK_GBS
+                roof["traffic"] = int(hbm_bytes)
+            for k in ("TCC_HIT_sum", "TCC_MISS_sum", "TD_TD_BUSY_sum", "TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES",
+                      "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU"):
+                if k in c:
+                    roof.setdefault("counters_per_launch", {})[k] = c[k]
+        if fracs:
+            bound = max(fracs, key=fracs.get)     # the limit the kernel is closest to
+            if bound == "valu":
+                roof.update(bound="valu", achieved=roof["valu"]["achieved_Tlaneops"], peak=roof["valu"]["peak_Tlaneops"],
+                            unit="Tlane-op/s", frac=roof["valu"]["frac"])
+            else:
+                roof.update(bound="hbm", achieved=roof["hbm"]["measured_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["frac"])
+        else:
+            # no stored counters for this workload: no fraction is claimed (run tools/round_profile.sh <config>)
+            roof.update(bound="unmeasured", achieved=None, peak=None, unit=None, frac=None, traffic=None)
+        roof.setdefault("traffic", None)
         out = {
             "metric": "Mrays/sec (incl. bounces)",
             "value": round(mrays, 2),
@@ -189,23 +331,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "strong" if (world > 1 and args.partition == "rows") else "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "bundled scene geometry/textures, synthetic camera batch" if args.synth_instances == 0 else "synthetic",
-            "config": {"workload": workload, "width": W, "height": H, "spp_per_gpu": spp, "max_bounces": args.bounces,
-                       "partition": "none" if world == 1 else args.partition, "mode": args.mode,
+            "config": {"workload": workload, "preset": args.config, "width": W, "height": H, "spp_per_gpu": spp,
+                       "spp_total": spp * world if args.partition == "samples" else spp, "max_bounces": args.bounces,
+                       "partition": "none" if world == 1 else args.partition, "ranks_seen_by_rccl": world, "mode": args.mode,
                        "wavefront_iterations": int(st_counts.iterations),
                        "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
-                       "spp_per_sec_1080p": round(total_paths / (elapsed / args.steps) / (1920 * 1080), 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": dom_kernel, "launches_per_step": launches,
-                         "avg_launch_ms": round(dom_ms / launches, 4),
-                         "algorithmic_bytes_per_launch": int(dom_bytes / launches),
-                         "frame_kernels_ms": round(k_ms, 3), "frame_algorithmic_bytes": int(abytes),
-                         "frame_algorithmic_GBps": round(abytes / (k_ms * 1e-3) / 1e9, 1),
-                         "bytes_per_ray": round(abytes / max(st_counts.rays, 1), 1)},
+                       "spp_per_sec_1080p": round(total_paths / step_s / (1920 * 1080), 2)},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, scene, args)
@@ -217,17 +353,20 @@ def main():
 
 def cpu_baseline(rt, scene, args):
     """The oracle (CPU restatement of the reference trace/shade code) timed on this box's host cores, on a
-    bounded sample of the same workload (same scene, resolution and bounce depth, fewer spp)."""
+    bounded sample of the same workload (same scene and bounce depth; fewer spp and, for large frames, a smaller
+    frame, sized for 10-30 s of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob  # baseline leg only
     cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
-    p = rt.default_params(scene.camera, spp=args.cpu_spp, width=args.width, height=args.height,
-                          max_bounces=args.bounces, flags=rt.F_DEFAULT | rt.F_STATS)
+    w, h, spp = args.width, args.height, min(args.cpu_spp, args.spp)
+    if args.config in ("c3", "c3is", "c4"):   # heavier per ray than c2: quarter frame, 4 spp
+        w, h, spp = w // 2, h // 2, min(4, spp)
+    p = rt.default_params(scene.camera, spp=spp, width=w, height=h, max_bounces=args.bounces, flags=rt.F_DEFAULT | rt.F_STATS)
     t0 = time.perf_counter()
     _, st = ob.render(scene, p, n_threads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same scene at {args.width}x{args.height}, {args.cpu_spp} of {args.spp} spp, {st.rays} rays in {dt:.1f} s"}
+            "sample": f"same scene at {w}x{h}, {spp} of {args.spp} spp, {st.rays} rays in {dt:.1f} s"}
 
 
 if __name__ == "__main__":
