@@ -21,7 +21,7 @@ $(LIBDIR)/librt_scene.so: $(PKG)/csrc/host/rt_scene.cpp include/rt_scene.h inclu
 
 $(LIBDIR)/librt_amd.so: $(PKG)/csrc/rt_core.hip $(wildcard $(PKG)/csrc/*.h) include/rt.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $<
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $< -ldl
 
 $(LIBDIR)/rtcli: $(PKG)/csrc/cli/rtcli.cpp $(LIBDIR)/librt_scene.so $(LIBDIR)/librt_amd.so include/rt.h include/rt_scene.h
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(LIBDIR) -lrt_scene -lrt_amd -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib

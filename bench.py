@@ -276,10 +276,11 @@ def main():
         # from the LDS node cache, the other inner items and every triangle test from L1/L2 (HBM only on a miss)
         lds_b = 64 * st_counts.dev_lds_inner_visits / launches
         l2_b = (64 * (st_counts.dev_inner_visits - st_counts.dev_lds_inner_visits) + 48 * st_counts.dev_tri_tests +
-                (64 + 48 + 48) * st_counts.hits + 12 * st_counts.texel_fetches + 64 * st_counts.light_tests) / launches
+                (64 + 48 + 48) * st_counts.hits + 12 * st_counts.texel_fetches + 64 * st_counts.dev_light_tests) / launches
         roof["device_requests"] = {
             "inner_items_visited": int(st_counts.dev_inner_visits), "of_those_from_lds": int(st_counts.dev_lds_inner_visits),
             "triangle_tests_run": int(st_counts.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
+            "light_tests_run": int(st_counts.dev_light_tests), "reference_walk_light_tests": int(st_counts.light_tests),
             "lds_GBps": round(lds_b / launch_s / 1e9, 1), "lds_peak_GBps": 150000.0,
             "l2_GBps": round(l2_b / launch_s / 1e9, 1), "l2_peak_GBps": 34500.0}
         roof["algorithmic_bytes_per_launch"] = int(dom_bytes / launches)

@@ -166,6 +166,7 @@ typedef struct rt_render_stats {
     uint64_t dev_inner_visits;     /* inner items visited: reference nodes and sub-tree nodes, 64 B each */
     uint64_t dev_lds_inner_visits; /* of those, served by the LDS node cache instead of L2 / HBM */
     uint64_t dev_tri_tests;        /* triangle tests really run, 48 B each */
+    uint64_t dev_light_tests;      /* light-triangle pdf tests really run (after the culling of light groups), 64 B each */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };
@@ -242,6 +243,38 @@ int rt_trace_rays(rt_context* ctx, const float* org_dir, size_t n, uint32_t flag
 #define RT_TRACE_NOALLOC_MAX_RAYS (1 << 18)
 int rt_trace_rays_noalloc(rt_context* ctx, const float* dev_org_dir, size_t n, uint32_t flags, int32_t* dev_prim_id,
                           float* dev_t, float* dev_hit_pos, float* dev_normal3, int sync);
+
+/* ---- several GPUs of one node from one process ----------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE (one GPU, one launch, src/main.cu:472-482).  BASELINE.json asks for the image to be
+ * partitioned over the 8 GPUs of a node by tile rows (RCCL gather) or by sample slices (RCCL sum-reduce) of the
+ * float accumulators.  An rt_comm owns one rt_context per device, renders on all of them at once (one host thread
+ * each) and combines on rank 0 with ONE collective per call: grouped ncclSend / ncclRecv of the band-packed rows + a
+ * de-interleave kernel, or ncclReduce(sum).  librccl is loaded at run time.  RT_COMM_LOCAL moves the same data
+ * with hipMemcpyPeerAsync and sums in rank order ((a0 + a1) + a2 ...): used when librccl is missing and by the tests
+ * on a one-GPU box (several ranks on ONE device, which RCCL refuses).  Rows: bit-identical to one GPU.  Samples: the
+ * difference to one GPU is the order of the float additions.  rt_comm_render accumulates into the root's image like
+ * rt_render does (rt_comm_reset starts over); band_rows <= 0 means 16. */
+enum { RT_PART_ROWS = 0, RT_PART_SAMPLES = 1 };
+enum { RT_COMM_RCCL = 0, RT_COMM_LOCAL = 1 };
+typedef struct rt_comm rt_comm;
+int rt_comm_create(rt_comm** out, const int* device_ids, int n_devices, int transport);
+void rt_comm_destroy(rt_comm* comm);
+const char* rt_comm_last_error(const rt_comm* comm);
+int rt_comm_size(const rt_comm* comm);
+int rt_comm_transport(const rt_comm* comm);               /* the transport in use (RT_COMM_LOCAL if librccl could not be loaded) */
+rt_context* rt_comm_context(rt_comm* comm, int rank);     /* owned by the comm */
+int rt_comm_upload_scene(rt_comm* comm, const rt_scene_desc* scene);   /* replicated on every device */
+int rt_comm_render(rt_comm* comm, const rt_render_params* params, int partition, int band_rows, rt_render_stats* stats);
+int rt_comm_reduce_sum(rt_comm* comm);    /* the combine steps alone (rt_comm_render calls them) */
+int rt_comm_gather_rows(rt_comm* comm);
+int rt_comm_reset(rt_comm* comm);
+int rt_comm_readback(rt_comm* comm, float* rgb, size_t n_floats, int mode);   /* the root's full image, RT_READ_* */
+/* Host-side statements of the two combine steps, no device needed (what the CPU tests check the index arithmetic
+ * and the summation order against): rows of `rank` under the band interleave (returns their number; rows may be
+ * NULL), the de-interleave of band-packed buffers, the rank-ordered sum. */
+int rt_band_rows_of_rank(int height, int band_rows, int n_ranks, int rank, int32_t* rows);
+int rt_host_gather_rows(const float* const* band_packed, int n_ranks, int width, int height, int band_rows, float* full);
+int rt_host_reduce_sum(const float* const* accums, int n_ranks, size_t n_floats, float* out);
 
 /* Inspection hook, no device needed: the layout rt_upload_scene copies to the
  * GPU, built in host memory.  The reference has no counterpart (it uploads

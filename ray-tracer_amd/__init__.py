@@ -69,7 +69,8 @@ class RenderStats(C.Structure):
                 ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64),
                 ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32),
-                ("dev_inner_visits", C.c_uint64), ("dev_lds_inner_visits", C.c_uint64), ("dev_tri_tests", C.c_uint64)]
+                ("dev_inner_visits", C.c_uint64), ("dev_lds_inner_visits", C.c_uint64), ("dev_tri_tests", C.c_uint64),
+                ("dev_light_tests", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -97,7 +98,10 @@ TRI_FLOATS = 25
 
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback", "rt_readback_rgb8",
               "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
-              "rt_trace_rays", "rt_trace_rays_noalloc", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy"]
+              "rt_trace_rays", "rt_trace_rays_noalloc", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy",
+              "rt_comm_create", "rt_comm_destroy", "rt_comm_last_error", "rt_comm_size", "rt_comm_transport", "rt_comm_context",
+              "rt_comm_upload_scene", "rt_comm_render", "rt_comm_reduce_sum", "rt_comm_gather_rows", "rt_comm_reset",
+              "rt_comm_readback", "rt_band_rows_of_rank", "rt_host_gather_rows", "rt_host_reduce_sum"]
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
@@ -178,6 +182,24 @@ def core_lib() -> C.CDLL:
         L.rt_layout_get.argtypes = [C.c_void_p, C.POINTER(LayoutInfo), C.POINTER(_fp), C.POINTER(_ip)]
         L.rt_layout_destroy.argtypes = [C.c_void_p]
         L.rt_layout_destroy.restype = None
+        L.rt_comm_create.argtypes = [C.POINTER(C.c_void_p), _ip, C.c_int, C.c_int]
+        L.rt_comm_destroy.argtypes = [C.c_void_p]
+        L.rt_comm_destroy.restype = None
+        L.rt_comm_last_error.argtypes = [C.c_void_p]
+        L.rt_comm_last_error.restype = C.c_char_p
+        L.rt_comm_size.argtypes = [C.c_void_p]
+        L.rt_comm_transport.argtypes = [C.c_void_p]
+        L.rt_comm_context.argtypes = [C.c_void_p, C.c_int]
+        L.rt_comm_context.restype = C.c_void_p
+        L.rt_comm_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
+        L.rt_comm_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_int, C.POINTER(RenderStats)]
+        L.rt_comm_reduce_sum.argtypes = [C.c_void_p]
+        L.rt_comm_gather_rows.argtypes = [C.c_void_p]
+        L.rt_comm_reset.argtypes = [C.c_void_p]
+        L.rt_comm_readback.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_int]
+        L.rt_band_rows_of_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip]
+        L.rt_host_gather_rows.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.rt_host_reduce_sum.argtypes = [C.POINTER(_fp), C.c_int, C.c_size_t, _fp]
         _core_lib = L
     return _core_lib
 
@@ -453,3 +475,60 @@ class Renderer:
         out = np.zeros_like(a)
         self._ck(self._L.rt_shade_hits(self._h, _ptr(a), a.shape[0], seed, _ptr(out)))
         return out
+
+
+PART_ROWS, PART_SAMPLES = 0, 1
+COMM_RCCL, COMM_LOCAL = 0, 1
+
+
+class Comm:
+    """Several GPUs from one process (rt_comm_*, include/rt.h): one context per device, one collective per frame."""
+
+    def __init__(self, device_ids, transport: int = COMM_RCCL):
+        self._L = core_lib()
+        self._h = C.c_void_p()
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        rc = self._L.rt_comm_create(C.byref(self._h), ids, len(device_ids), transport)
+        if rc != 0:
+            raise RuntimeError(f"rt_comm_create failed ({rc})")
+        self._shape = (0, 0)
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"rt_comm error {rc}: {self._L.rt_comm_last_error(self._h).decode()}")
+
+    @property
+    def size(self) -> int:
+        return self._L.rt_comm_size(self._h)
+
+    @property
+    def transport(self) -> int:
+        return self._L.rt_comm_transport(self._h)
+
+    def upload(self, scene: Scene):
+        self._ck(self._L.rt_comm_upload_scene(self._h, C.byref(scene.desc)))
+
+    def render(self, params: RenderParams, partition: int, band_rows: int = 16) -> RenderStats:
+        st = RenderStats()
+        self._ck(self._L.rt_comm_render(self._h, C.byref(params), partition, band_rows, C.byref(st)))
+        self._shape = (params.cam.height, params.cam.width)
+        return st
+
+    def reset(self):
+        self._ck(self._L.rt_comm_reset(self._h))
+
+    def readback(self, mode: int = READ_RAW_SUM) -> np.ndarray:
+        out = np.empty(self._shape + (3,), np.float32)
+        self._ck(self._L.rt_comm_readback(self._h, _ptr(out), out.size, mode))
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.rt_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

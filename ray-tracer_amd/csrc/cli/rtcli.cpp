@@ -5,6 +5,7 @@
 //
 //   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
 //         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]
+//         [--devices 0-7 | 0,2,5] [--partition rows|samples]     several GPUs of the node (rt_comm_*: RCCL gather / sum-reduce)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -17,14 +18,38 @@
 
 static int usage() {
     fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
-                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]\n");
+                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]\n"
+                    "             [--devices 0-7|0,2,5] [--partition rows|samples]\n");
     return 2;
+}
+
+// "0-7" or "0,2,5" (or a mix) -> device ids
+static bool parse_devices(const std::string& spec, std::vector<int>& out) {
+    size_t i = 0;
+    while (i < spec.size()) {
+        size_t j = spec.find(',', i);
+        if (j == std::string::npos) j = spec.size();
+        const std::string part = spec.substr(i, j - i);
+        int a = 0, b = 0;
+        if (sscanf(part.c_str(), "%d-%d", &a, &b) == 2) {
+            if (a < 0 || b < a) return false;
+            for (int d = a; d <= b; d++) out.push_back(d);
+        } else if (sscanf(part.c_str(), "%d", &a) == 1 && a >= 0) {
+            out.push_back(a);
+        } else {
+            return false;
+        }
+        i = j + 1;
+    }
+    return !out.empty();
 }
 
 int main(int argc, char** argv) {
     std::string scene, asset_root, out = "output.png", env;
     int spp = -1, bounces = -1, W = 0, H = 0, device = 0;
     unsigned seed = 37811;
+    std::vector<int> devices;
+    int partition = RT_PART_ROWS;
     bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -37,6 +62,8 @@ int main(int argc, char** argv) {
         else if (a == "--bounces") bounces = atoi(next());
         else if (a == "--seed") seed = (unsigned)strtoul(next(), nullptr, 10);
         else if (a == "--device") device = atoi(next());
+        else if (a == "--devices") { if (!parse_devices(next(), devices)) return usage(); }
+        else if (a == "--partition") { const std::string v = next(); if (v == "rows") partition = RT_PART_ROWS; else if (v == "samples") partition = RT_PART_SAMPLES; else return usage(); }
         else if (a == "--size") { if (sscanf(next(), "%dx%d", &W, &H) != 2) return usage(); }
         else if (a == "--hdr") hdr = true;            // HDRI_EXPORT, config.h:12
         else if (a == "--spheres") spheres = true;    // ENABLE_SPHERES, config.h:13
@@ -70,15 +97,6 @@ int main(int argc, char** argv) {
     printf("num important tris: %d\n", desc.n_light_tris);          // main.cu:442
     printf("Image data length: %zu\n", desc.n_tex_floats);          // main.cu:456
 
-    rt_context* ctx = nullptr;
-    if (rt_create(&ctx, device) != RT_OK) {
-        fprintf(stderr, "rt_create failed: no usable HIP device (there is no CPU fallback)\n");
-        return 1;
-    }
-    if (rt_upload_scene(ctx, &desc) != RT_OK) {
-        fprintf(stderr, "upload: %s\n", rt_last_error(ctx));
-        return 1;
-    }
     rt_render_params p;
     memset(&p, 0, sizeof(p));
     p.cam = cam;
@@ -93,8 +111,46 @@ int main(int argc, char** argv) {
     p.band_stride = 1;
     p.background[0] = 1.0f; p.background[1] = 1.0f; p.background[2] = 0.05f;  // config.h:7
     p.background_brightness = 0.5f;                                          // config.h:6
-    printf("begin rendering\n");                                             // main.cu:470
+    std::vector<float> img((size_t)p.cam.width * p.cam.height * 3);
     rt_render_stats st;
+
+    if (!devices.empty()) {  // several GPUs: image rows (RCCL gather) or sample slices (RCCL sum-reduce) over the devices
+        rt_comm* comm = nullptr;
+        if (rt_comm_create(&comm, devices.data(), (int)devices.size(), RT_COMM_RCCL) != RT_OK) {
+            fprintf(stderr, "rt_comm_create failed: devices not usable (each id once, all present)\n");
+            return 1;
+        }
+        printf("%d devices, %s, transport %s\n", rt_comm_size(comm), partition == RT_PART_ROWS ? "image rows in bands of 16" : "sample slices",
+               rt_comm_transport(comm) == RT_COMM_RCCL ? "RCCL" : "local copies");
+        if (rt_comm_upload_scene(comm, &desc) != RT_OK) { fprintf(stderr, "upload: %s\n", rt_comm_last_error(comm)); return 1; }
+        printf("begin rendering\n");
+        const auto t0 = std::chrono::steady_clock::now();
+        if (rt_comm_render(comm, &p, partition, 16, &st) != RT_OK) { fprintf(stderr, "render: %s\n", rt_comm_last_error(comm)); return 1; }
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("done rendering\nRender time: %g ms (slowest device's kernels %g ms)\n", wall_ms, st.kernel_ms);
+        if (want_stats)
+            printf("paths %llu rays %llu (%.1f Mrays/s)\n", (unsigned long long)st.paths, (unsigned long long)st.rays, st.rays / (wall_ms * 1e3));
+        if (rt_comm_readback(comm, img.data(), img.size(), hdr ? RT_READ_AVERAGE : RT_READ_TONEMAPPED) != RT_OK) {
+            fprintf(stderr, "readback: %s\n", rt_comm_last_error(comm));
+            return 1;
+        }
+        if (rt_image_save(out.c_str(), img.data(), p.cam.width, p.cam.height) != RT_OK) { fprintf(stderr, "save: %s\n", rt_scene_last_error()); return 1; }
+        printf("Saved output\n");
+        rt_comm_destroy(comm);
+        rt_scene_free(hs);
+        return 0;
+    }
+
+    rt_context* ctx = nullptr;
+    if (rt_create(&ctx, device) != RT_OK) {
+        fprintf(stderr, "rt_create failed: no usable HIP device (there is no CPU fallback)\n");
+        return 1;
+    }
+    if (rt_upload_scene(ctx, &desc) != RT_OK) {
+        fprintf(stderr, "upload: %s\n", rt_last_error(ctx));
+        return 1;
+    }
+    printf("begin rendering\n");                                             // main.cu:470
     if (rt_render(ctx, &p, &st) != RT_OK) {
         fprintf(stderr, "render: %s\n", rt_last_error(ctx));
         return 1;
@@ -104,7 +160,6 @@ int main(int argc, char** argv) {
         printf("paths %llu rays %llu (%.1f Mrays/s) inner %llu leaf %llu tri %llu\n", (unsigned long long)st.paths,
                (unsigned long long)st.rays, st.rays / (st.kernel_ms * 1e3), (unsigned long long)st.inner_visits,
                (unsigned long long)st.leaf_visits, (unsigned long long)st.tri_tests);
-    std::vector<float> img((size_t)p.cam.width * p.cam.height * 3);
     if (rt_readback(ctx, img.data(), img.size(), hdr ? RT_READ_AVERAGE : RT_READ_TONEMAPPED) != RT_OK) {
         fprintf(stderr, "readback: %s\n", rt_last_error(ctx));
         return 1;

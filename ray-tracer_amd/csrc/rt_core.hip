@@ -177,15 +177,15 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {  // wave-reduce, one atomic per counter per wave
-        uint32_t v[11] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri};
+        uint32_t v[12] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights};
 #pragma unroll
-        for (int i = 0; i < 11; i++) {
+        for (int i = 0; i < 12; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
         }
 #ifdef RT_CYCLE_PROF
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 16; i++) {
             unsigned long long s = cn.prof[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[16 + i], s);
@@ -460,6 +460,16 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         const bool at_inner = trav_at_inner(sc, t);
         const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
         const unsigned long long mLeaf = __ballot(at_leaf);
+#ifdef RT_CYCLE_PROF
+        {   // lane census of this iteration: who steps, who waits for what
+            const bool leaf_iter = __popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0;
+            const int base = leaf_iter ? 12 : 8;
+            RT_PROF_COUNT(cn, base, 1);
+            RT_PROF_COUNT(cn, base + 1, (unsigned long long)__popcll(__ballot(at_inner)));
+            RT_PROF_COUNT(cn, base + 2, (unsigned long long)__popcll(mLeaf));
+            RT_PROF_COUNT(cn, base + 3, (unsigned long long)__popcll(__ballot((unsigned)(t.cur + 2) < 2u)));
+        }
+#endif
         if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
@@ -491,15 +501,15 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {
-        uint32_t v[11] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri};
+        uint32_t v[12] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights};
 #pragma unroll
-        for (int i = 0; i < 11; i++) {
+        for (int i = 0; i < 12; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
         }
 #ifdef RT_CYCLE_PROF
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 16; i++) {
             unsigned long long s = cn.prof[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[16 + i], s);
@@ -709,10 +719,10 @@ __global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Para
         wf.rayq[2 * (size_t)pos + 1] = make_float4(rd.x, rd.y, rd.z, 0.f);
     }
     if (STATS) {
-        uint32_t v[4] = {cn.paths, cn.hits, cn.texels, cn.lights};
-        const int idx[4] = {0, 5, 6, 7};
+        uint32_t v[5] = {cn.paths, cn.hits, cn.texels, cn.lights, cn.dev_lights};
+        const int idx[5] = {0, 5, 6, 7, 11};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 5; i++) {
             unsigned long long t = v[i];
             for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
             if (lane == 0 && t) atomicAdd(&stats[idx[i]], t);
@@ -2163,10 +2173,14 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
                             "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass)(shading part %.0f); wave lifetimes %llu cycles; kernel %.3f ms\n",
                     h[16], h[17], h[16] ? (double)h[17] / h[16] : 0.0, h[18], h[16] ? (double)h[18] / h[16] : 0.0, h[19], h[20],
                     h[19] ? (double)h[20] / h[19] : 0.0, h[21], h[19] ? (double)h[21] / h[19] : 0.0, h[19] ? (double)h[23] / h[19] : 0.0, h[22], stats->kernel_ms);
+            fprintf(stderr, "[rt prof] census per iteration (lanes at inner / at leaf / waiting for a vertex pass): inner iterations %llu: %.1f / %.1f / %.1f; "
+                            "leaf iterations %llu: %.1f / %.1f / %.1f\n",
+                    h[24], h[24] ? (double)h[25] / h[24] : 0.0, h[24] ? (double)h[26] / h[24] : 0.0, h[24] ? (double)h[27] / h[24] : 0.0,
+                    h[28], h[28] ? (double)h[29] / h[28] : 0.0, h[28] ? (double)h[30] / h[28] : 0.0, h[28] ? (double)h[31] / h[28] : 0.0);
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
-            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10];
+            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11];
         }
     }
     return RT_OK;
@@ -2367,3 +2381,5 @@ int rt_shade_hits(rt_context* c, const float* in, size_t n, uint32_t seed, float
 }
 
 }  // extern "C"
+
+#include "rt_comm_impl.h"

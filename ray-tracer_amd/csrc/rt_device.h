@@ -180,15 +180,15 @@ struct Counters {
     uint32_t paths, rays, inner, leaf, tri, hits, texels, lights;
     // what the DEVICE really does (the eight above count the reference's walk, which a sub-tree root stands in for):
     // inner items visited (reference nodes and sub-tree nodes), of those served by the LDS node cache, triangle tests run
-    uint32_t dev_inner, dev_cached, dev_tri;
+    uint32_t dev_inner, dev_cached, dev_tri, dev_lights;  // (dev_lights: light-triangle pdf tests really run, after the group culling)
 #ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
-    unsigned long long prof[8];  // 0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
+    unsigned long long prof[16];  // (8..15: lane census per iteration kind, rt_render_paths_kernel)   0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
 #endif
     __device__ __forceinline__ void clear() {
         paths = rays = inner = leaf = tri = hits = texels = lights = 0;
-        dev_inner = dev_cached = dev_tri = 0;
+        dev_inner = dev_cached = dev_tri = dev_lights = 0;
 #ifdef RT_CYCLE_PROF
-        for (int i = 0; i < 8; i++) prof[i] = 0;
+        for (int i = 0; i < 16; i++) prof[i] = 0;
 #endif
     }
 };
@@ -944,7 +944,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323
                 const float4* L = sc.lights + 5 * (size_t)i;
                 const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
-                if (STATS) cn.lights++;
+                if (STATS) { cn.lights++; cn.dev_lights++; }
                 pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x),
                                       mk(l2.y, l2.z, l2.w), l3.x) / (float)sc.n_lights;
             }
@@ -1033,6 +1033,7 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
                 const int i = base + gs * RT_LIGHT_GROUP + sub;
                 float term = 0.0f;
                 if (gs >= 0 && i < sc.n_lights) {
+                    if (STATS) cn.dev_lights++;
                     const float4* L = sc.lights + 5 * (size_t)i;
                     const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
                     term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
