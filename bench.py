@@ -19,6 +19,8 @@ Prints ONE JSON line on rank 0.  `roofline` names the limit that binds (see DESI
   valu  useful vector lane-operations (SQ_THREAD_CYCLES_VALU, active lanes only) per second against the chip's issue
         peak for plain f32 vector instructions (tools/micro/valu_peak.hip)           = issue_util x lane_util
   hbm   measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) per second against 8 TB/s
+  td    busy fraction of the texture-data return path (TD_TD_BUSY / elapsed cycles per CU): every divergent 16-byte
+        request of a lane costs it a cycle or more, so scenes whose nodes do not fit the LDS cache run into it
 The counters are a STORED measurement (profiles/r*_pmc_<workload>.json, written by tools/round_profile.sh with
 rocprofv3 in separate --pmc passes); counts per launch are deterministic for a workload and a build, the launch
 duration is measured live with HIP events.  `algorithmic_GBps` keeps SURVEY 8(d)'s figure (bytes of the REFERENCE's
@@ -308,6 +310,17 @@ def main():
                                "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)}
                 fracs["hbm"] = hbm_bytes / launch_s / 1e9 / HBM_PEAK_GBS
                 roof["traffic"] = int(hbm_bytes)
+            if "TD_TD_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+                # texture-data return path of the vector memory pipeline (one per CU): busy cycles / elapsed cycles.  A divergent
+                # 16-byte request occupies it ~1-2.5 cycles per lane (tools/micro/gather_bench.hip): at ~1 it is the limit
+                cyc = c["GRBM_GUI_ACTIVE"] / 8.0            # rocprofv3 sums GRBM over the 8 XCDs
+                td = c["TD_TD_BUSY_sum"] / (256.0 * cyc)
+                roof["td"] = {"busy_frac": round(td, 4), "ta_busy_frac": round(c.get("TA_TA_BUSY_sum", 0.0) / (256.0 * cyc), 4),
+                              "vmem_read_wave_insts_per_launch": c.get("SQ_INSTS_VMEM_RD"), "note": "stored ratio (same pass as the counters)"}
+                fracs["td"] = td
+            if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+                roof["lds"] = {"busy_frac": round(c["SQ_LDS_IDX_ACTIVE"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4),
+                               "bank_conflict_share": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 4)}
             for k in ("TCC_HIT_sum", "TCC_MISS_sum", "TD_TD_BUSY_sum", "TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES",
                       "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU"):
                 if k in c:
@@ -317,6 +330,8 @@ def main():
             if bound == "valu":
                 roof.update(bound="valu", achieved=roof["valu"]["achieved_Tlaneops"], peak=roof["valu"]["peak_Tlaneops"],
                             unit="Tlane-op/s", frac=roof["valu"]["frac"])
+            elif bound == "td":
+                roof.update(bound="td", achieved=roof["td"]["busy_frac"], peak=1.0, unit="busy fraction of the texture-data path", frac=roof["td"]["busy_frac"])
             else:
                 roof.update(bound="hbm", achieved=roof["hbm"]["measured_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["frac"])
         else:

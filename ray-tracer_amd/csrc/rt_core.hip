@@ -251,11 +251,14 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
                                                                               int stack_entries, int chunk_k0, int chunk_S,
-                                                                              unsigned int n_paths) {
+                                                                              unsigned int n_paths, int n_mats_lds) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
     int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
+    // the material table behind the stacks (n_mats_lds = 0: too many materials, they stay in device memory)
+    const int mats_lds = n_mats_lds > 0 ? (int)(RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16) : -1;
+    for (int i = threadIdx.x; i < 3 * n_mats_lds; i += 64 * RT_MEGA_WAVES) rt_lds[mats_lds + i] = sc.mats[i];
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                             // scattered inside the volume: `continue`, main.cu:350-352
                         } else {
                             if (STATS) cn.hits++;
-                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn, COOP ? &lq : nullptr)) {  // main.cu:357-360
+                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn, COOP ? &lq : nullptr, mats_lds)) {  // main.cu:357-360
                                 e = ray.emission * ray.thr;
                                 alive = false;
                             } else if (!COOP || !lq.pending) {
@@ -464,10 +467,12 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         {   // lane census of this iteration: who steps, who waits for what
             const bool leaf_iter = __popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0;
             const int base = leaf_iter ? 12 : 8;
+            const unsigned long long nI = (unsigned long long)__popcll(__ballot(at_inner)), nL = (unsigned long long)__popcll(mLeaf),
+                                     nV = (unsigned long long)__popcll(__ballot((unsigned)(t.cur + 2) < 2u));  // (votes by the whole wave)
             RT_PROF_COUNT(cn, base, 1);
-            RT_PROF_COUNT(cn, base + 1, (unsigned long long)__popcll(__ballot(at_inner)));
-            RT_PROF_COUNT(cn, base + 2, (unsigned long long)__popcll(mLeaf));
-            RT_PROF_COUNT(cn, base + 3, (unsigned long long)__popcll(__ballot((unsigned)(t.cur + 2) < 2u)));
+            RT_PROF_COUNT(cn, base + 1, nI);
+            RT_PROF_COUNT(cn, base + 2, nL);
+            RT_PROF_COUNT(cn, base + 3, nV);
         }
 #endif
         if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
@@ -1915,14 +1920,16 @@ int ensure_wavefront(rt_context* c, int n_slots) {
 // Launch shape of the trace kernel for the uploaded scene: one 1024-thread block per CU whose LDS
 // (160 KiB) holds the per-lane stacks (bvh depth entries) and as much of the top of the tree as fits.
 struct TraceCfg {
-    int grid, n_cached, stack_entries;
+    int grid, n_cached, stack_entries, n_mats_lds;
     size_t lds_bytes;
 };
 
-TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES) {
+#define RT_LDS_MATS_MAX 128  // material tables up to this size go to LDS in the path kernel (48 B each)
+TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = false) {
     TraceCfg t;
     t.stack_entries = std::max(c->bvh_depth, 1);
-    const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int);
+    t.n_mats_lds = (with_mats && c->sc.n_mats <= RT_LDS_MATS_MAX && !getenv("RT_NO_LDS_MATS")) ? c->sc.n_mats : 0;
+    const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48;
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
@@ -1940,7 +1947,7 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
     return RT_OK;
 }
 
-typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int);
+typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int, int);
 paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop) {
 #define RT_V4(C) \
     rt_render_paths_kernel<false, false, false, C>, rt_render_paths_kernel<true, false, false, C>, \
@@ -1985,7 +1992,7 @@ int render_lockstep(rt_context* c, const Params& P, float* accum, bool want_stat
 // Path-parallel fused kernel: the call's samples in chunks of S; per chunk one persistent launch that
 // writes one radiance per path, and one pass that adds them to the accumulator in sample order.
 int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, bool profile, rt_render_stats* out) {
-    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES);
+    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true);
     int rc = set_mega_lds(c, tc);
     if (rc != RT_OK) return rc;
     const size_t slots = (size_t)P.n_tiles * 64;  // pixels incl. the padding of edge tiles
@@ -2028,7 +2035,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used], c->stream));
         }
         hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, c->d_samples, c->d_tile_counter,
-                           c->d_stats, tc.n_cached, tc.stack_entries, (int)k0, s, n_paths);
+                           c->d_stats, tc.n_cached, tc.stack_entries, (int)k0, s, n_paths, tc.n_mats_lds);
         if (timed) {
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
             ev_used += 2;

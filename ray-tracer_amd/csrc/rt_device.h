@@ -804,7 +804,7 @@ template <bool STATS>
 // The bounce's dimensions 8+8j .. 15+8j are Philox blocks bb and bb+1 (bb = 2 + 2j): A = dims k0..k3,
 // B = dims k4..k7, consumed in the reference's call order.
 __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, const Rng& rng,
-                                               uint32_t bb, Counters& cn, LightQuery* lq = nullptr) {
+                                               uint32_t bb, Counters& cn, LightQuery* lq = nullptr, int mats_lds = -1) {
     const HitFrame hf = hit_frame(sc, tri, hitPos);
     const f3 normal = hf.normal;
     int type = 127;  // out-of-range material id -> "the color of error"
@@ -812,8 +812,19 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
     float p1 = 0.f, p2 = 0.f;
     int off0 = -1, off1 = -1, off2 = -1, tw = 0, th = 0;
     if (hf.mat >= 0 && hf.mat < sc.n_mats) {
-        const float4* m = sc.mats + 3 * (size_t)hf.mat;
-        const float4 m0 = m[0], m1 = m[1], m2 = m[2];
+        float4 m0, m1, m2;
+        if (mats_lds >= 0) {  // the material table sits in LDS behind the stacks (rt_render_paths_kernel): three ds_read_b128
+            typedef float v4f __attribute__((ext_vector_type(4)));  // instead of four or five narrow global requests per hit
+            typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f;
+            const lds_v4f c = (lds_v4f)rt_lds + mats_lds + 3 * hf.mat;
+            const v4f a0 = c[0], a1 = c[1], a2 = c[2];
+            m0 = make_float4(a0.x, a0.y, a0.z, a0.w);
+            m1 = make_float4(a1.x, a1.y, a1.z, a1.w);
+            m2 = make_float4(a2.x, a2.y, a2.z, a2.w);
+        } else {
+            const float4* m = sc.mats + 3 * (size_t)hf.mat;
+            m0 = m[0]; m1 = m[1]; m2 = m[2];
+        }
         type = __float_as_int(m0.x);
         clr = mk(m0.y, m0.z, m0.w);
         p1 = m1.x;
