@@ -480,9 +480,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
                 trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
-#if RT_LEAF_STEPS > 1
-                if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
-#endif
+#pragma unroll
+                for (int k = 1; k < RT_LEAF_STEPS; k++)
+                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
             }
         } else {
             if (at_inner) {
@@ -1330,7 +1330,7 @@ struct HostLayout {
     std::vector<float> items, cold, mats, lights, spheres;
     std::vector<int> place;  // reference triangle id -> place in the item stream
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
-    size_t light_box_off = 0;  // floats into `lights`
+    size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
 };
 
@@ -1716,31 +1716,76 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         d[11] = i2f((int)m.image_height);
     }
 
-    // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once
-    const int n_light_groups = (std::max(s->n_light_tris, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
-    const size_t light_box_off = (size_t)std::max(s->n_light_tris, 1) * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records
+    // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once.  With enough lights for the
+    //      wave-cooperative loop (rt_device.h) the records are stored in SPATIAL order (Morton code of the centroid), so
+    //      that a group of RT_LIGHT_GROUP consecutive records is a small patch with a tight box; place[i] says where the
+    //      reference's i-th light went, and every record carries its reference index (the sum over the lights is formed
+    //      in that order, see wave_light_pdf).
+    const int nl = s->n_light_tris;
+    const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
+    const size_t light_box_off = (size_t)std::max(nl, 1) * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records
+    const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
     std::vector<float>& lights = L.lights;
-    lights.assign(light_box_off + (size_t)n_light_groups * 8, 0.f);
+    lights.assign(light_place_off + (size_t)((std::max(nl, 1) + 3) & ~3), 0.f);
     for (int g = 0; g < n_light_groups; g++)
         for (int k = 0; k < 3; k++) {
             lights[light_box_off + (size_t)g * 8 + k] = 3e38f;
             lights[light_box_off + (size_t)g * 8 + 4 + k] = -3e38f;
         }
-    for (int i = 0; i < s->n_light_tris; i++) {
+    for (int i = 0; i < nl; i++) {
         const int off = s->light_tris[i];
         if (off < 0 || off % RT_TRI_FLOATS || (size_t)off + RT_TRI_FLOATS > s->n_tri_floats)
             return fail(RT_ERR_INVALID, "light triangle offset out of range");
-        const float* t = tris + off;
+    }
+    std::vector<int> light_order((size_t)std::max(nl, 1));  // light_order[j] = reference index of the light stored at j
+    for (int i = 0; i < nl; i++) light_order[(size_t)i] = i;
+    if (nl >= RT_LIGHTS_COOP_MIN && !getenv("RT_LIGHTS_UNSORTED")) {
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        std::vector<float> cen((size_t)nl * 3);
+        for (int i = 0; i < nl; i++) {
+            const float* t = tris + s->light_tris[i];
+            for (int k = 0; k < 3; k++) {
+                const float cc = (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+                cen[(size_t)i * 3 + k] = cc;
+                lo[k] = std::min(lo[k], cc);
+                hi[k] = std::max(hi[k], cc);
+            }
+        }
+        auto spread = [](unsigned v) {  // 10 bits -> every third bit
+            v &= 1023u;
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        std::vector<unsigned> code((size_t)nl);
+        for (int i = 0; i < nl; i++) {
+            unsigned q[3];
+            for (int k = 0; k < 3; k++) {
+                const float w = hi[k] - lo[k];
+                const float u = w > 0.f ? (cen[(size_t)i * 3 + k] - lo[k]) / w : 0.f;
+                q[k] = (unsigned)std::min(1023.f, std::max(0.f, u * 1024.f));
+            }
+            code[(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        std::stable_sort(light_order.begin(), light_order.begin() + nl, [&](int a, int b) { return code[(size_t)a] < code[(size_t)b]; });
+    }
+    for (int j = 0; j < nl; j++) {
+        const int i = light_order[(size_t)j];
+        const float* t = tris + s->light_tris[i];
         const H3 p1{t[0], t[1], t[2]}, p2{t[3], t[4], t[5]}, p3{t[6], t[7], t[8]};
         const H3 e1 = hsub(p2, p1), e2 = hsub(p3, p1);
         const H3 cr = hcross(e1, e2);
         const H3 nrm = hnormalize(cr);
         const float area = 0.5f * hlen(cr);
-        float* L = &lights[(size_t)i * 20];
-        L[0] = p1.x; L[1] = p1.y; L[2] = p1.z; L[3] = e1.x; L[4] = e1.y; L[5] = e1.z;
-        L[6] = e2.x; L[7] = e2.y; L[8] = e2.z; L[9] = nrm.x; L[10] = nrm.y; L[11] = nrm.z;
-        L[12] = area; L[13] = p2.x; L[14] = p2.y; L[15] = p2.z; L[16] = p3.x; L[17] = p3.y; L[18] = p3.z; L[19] = 0.f;
-        float* B = &lights[light_box_off + (size_t)(i / RT_LIGHT_GROUP) * 8];
+        float* Lr = &lights[(size_t)j * 20];
+        Lr[0] = p1.x; Lr[1] = p1.y; Lr[2] = p1.z; Lr[3] = e1.x; Lr[4] = e1.y; Lr[5] = e1.z;
+        Lr[6] = e2.x; Lr[7] = e2.y; Lr[8] = e2.z; Lr[9] = nrm.x; Lr[10] = nrm.y; Lr[11] = nrm.z;
+        Lr[12] = area; Lr[13] = p2.x; Lr[14] = p2.y; Lr[15] = p2.z; Lr[16] = p3.x; Lr[17] = p3.y; Lr[18] = p3.z;
+        Lr[19] = i2f(i);                                    // the light's place in the reference's list
+        lights[light_place_off + (size_t)i] = i2f(j);
+        float* B = &lights[light_box_off + (size_t)(j / RT_LIGHT_GROUP) * 8];
         for (int k = 0; k < 3; k++) {
             B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
             B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
@@ -1770,6 +1815,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.n_tris = ntri;
     L.depth = deepest;
     L.light_box_off = light_box_off;
+    L.light_place_off = light_place_off;
     L.scene_scale = scene_scale;
     L.box_pad = box_pad;
     timer.stage("materials, lights, spheres");
@@ -1805,6 +1851,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.mats = (const float4*)c->d_mats;
     sc.lights = (const float4*)c->d_lights;
     sc.light_boxes = sc.lights + L.light_box_off / 4;
+    sc.light_place = (const int*)((const float*)c->d_lights + L.light_place_off);
     sc.spheres = (const float4*)c->d_spheres;
     sc.tex = (const float*)c->d_tex;
     sc.n_tex = (long long)s->n_tex_floats;

@@ -50,7 +50,7 @@ namespace rtd {
 // leaf visit and all the leaf's triangle tests, like the walk it replaces.
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
-// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) pad
+// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) reference index (int bits)
 // light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [16 g, 16 g + 16), behind the light records
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
@@ -60,6 +60,7 @@ struct Scene {
     const float4* mats;
     const float4* lights;
     const float4* light_boxes;
+    const int* light_place;  // reference light index -> record (records are in spatial order when the wave-cooperative loop is used)
     const float4* spheres;
     const float* tex;
     long long n_tex;
@@ -924,7 +925,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             if (sc.n_lights > 0) {
                 if (u01(A.x) < 0.5f) {  // dims k0 (choice), k1 (raw pick), k2, k3
                     const uint32_t pick = A.y % (uint32_t)sc.n_lights;
-                    const float4* L = sc.lights + 5 * (size_t)pick;
+                    const float4* L = sc.lights + 5 * (size_t)sc.light_place[pick];
                     const float4 l0 = L[0], l3 = L[3], l4 = L[4];
                     outgoing = itri_sample(hitPos, u01(A.z), u01(A.w), mk(l0.x, l0.y, l0.z), mk(l3.y, l3.z, l3.w), mk(l4.x, l4.y, l4.z));
                     sampledLight = true;
@@ -952,8 +953,8 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
                 return false;
             }
             float pdf_light = 0.0f;
-            for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323
-                const float4* L = sc.lights + 5 * (size_t)i;
+            for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323, in the reference's order
+                const float4* L = sc.lights + 5 * (size_t)sc.light_place[i];
                 const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
                 if (STATS) { cn.lights++; cn.dev_lights++; }
                 pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x),
@@ -999,17 +1000,57 @@ __device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, co
 }
 
 // The light loop of reflectType5 for every lane with a pending query.  Call with the wave converged.  Same sum as
-// the lane's own loop: terms are added in light order, and the terms left out are the +0 of triangles the
-// direction misses (x + 0 = x).  Per pass over RT_LIGHT_CHUNK lights: every waiting lane marks the groups of
+// the lane's own loop: the terms left out are the +0 of triangles the direction misses (x + 0 = x), and the nonzero
+// terms are added in the REFERENCE's light order.  The records are stored in spatial order (upload), so the order
+// of the tests is not the order of the sum: up to two nonzero terms commute ((0 + a) + b == (0 + b) + a bit for bit),
+// which is every query but the rare one whose direction crosses three or more lights; those are summed again by
+// selection (wave_light_pdf_ordered).  Per pass over RT_LIGHT_CHUNK lights: every waiting lane marks the groups of
 // RT_LIGHT_GROUP lights whose bounds its ray can reach (all lanes at once, bounds through the scalar cache), then
 // lane after lane the wave tests the marked groups' triangles, four groups per step.
 #define RT_LIGHT_GROUP 16
 #define RT_LIGHT_CHUNK (64 * RT_LIGHT_GROUP)
+
+// Exact sum for ONE query (wave-uniform hp, og) whatever the number of nonzero terms: pass after pass over all the
+// lights, each pass adds the term of the smallest reference index not added yet.
+template <bool STATS>
+__device__ __forceinline__ float wave_light_pdf_ordered(const Scene& sc, f3 hp, f3 og, Counters& cn) {
+    const int lane = threadIdx.x & 63;
+    float acc = 0.0f;
+    int last = -1;
+    for (;;) {
+        int best = 0x7fffffff;
+        float bestTerm = 0.0f;
+        for (int i0 = 0; i0 < sc.n_lights; i0 += 64) {
+            const int i = i0 + lane;
+            float term = 0.0f;
+            int oi = 0x7fffffff;
+            if (i < sc.n_lights) {
+                if (STATS) cn.dev_lights++;
+                const float4* L = sc.lights + 5 * (size_t)i;
+                const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4];
+                term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w), l3.x) /
+                       (float)sc.n_lights;
+                oi = __float_as_int(l4.w);
+            }
+            for (unsigned long long h = __ballot(term != 0.0f && oi > last); h; h &= h - 1) {
+                const int l = __ffsll((long long)h) - 1;
+                const int o = __builtin_amdgcn_readlane(oi, l);
+                if (o < best) { best = o; bestTerm = lane_f(term, l); }
+            }
+        }
+        if (best == 0x7fffffff) break;
+        acc += bestTerm;
+        last = best;
+    }
+    return acc;
+}
+
 template <bool STATS>
 __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuery& q, Counters& cn) {
     const int lane = threadIdx.x & 63;
     const int slot = lane / RT_LIGHT_GROUP, sub = lane % RT_LIGHT_GROUP;
     float result = 0.0f;
+    int nonzero = 0;  // nonzero terms of this lane's query so far (over all chunks)
     BoxRay br;
     br.set(q.hitPos, q.outgoing);
     for (int base = 0; base < sc.n_lights; base += RT_LIGHT_CHUNK) {
@@ -1031,6 +1072,7 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
             unsigned long long gm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), ow) << 32) |
                                     (unsigned)__builtin_amdgcn_readlane((int)mine, ow);
             float acc = lane_f(result, ow);
+            int cnt = __builtin_amdgcn_readlane(nonzero, ow);
             while (gm) {
                 int g[64 / RT_LIGHT_GROUP];
 #pragma unroll
@@ -1050,10 +1092,21 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
                     term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
                                     l3.x) / (float)sc.n_lights;
                 }
-                for (unsigned long long h = __ballot(term != 0.0f); h; h &= h - 1) acc += lane_f(term, __ffsll((long long)h) - 1);
+                for (unsigned long long h = __ballot(term != 0.0f); h; h &= h - 1) {
+                    cnt++;
+                    acc += lane_f(term, __ffsll((long long)h) - 1);  // (meaningful while cnt <= 2; beyond, the query is summed again below)
+                }
             }
-            if (lane == ow) result = acc;
+            if (lane == ow) { result = acc; nonzero = cnt; }
         }
+    }
+    // three or more nonzero terms: their sum depends on the order; form it in the reference's
+    for (unsigned long long m = __ballot(q.pending && nonzero > 2); m; m &= m - 1) {
+        const int ow = __ffsll((long long)m) - 1;
+        const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
+        const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
+        const float exact = wave_light_pdf_ordered<STATS>(sc, hp, og, cn);
+        if (lane == ow) result = exact;
     }
     if (STATS && q.pending) cn.lights += (uint32_t)sc.n_lights;
     return result;

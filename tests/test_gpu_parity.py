@@ -198,6 +198,40 @@ def test_light_loop_over_several_chunks(ob, rt, gpu, n, frac):
         assert st.light_tests == ost.light_tests and st.light_tests > 0, mode
 
 
+@pytest.mark.parametrize("mode", ["megakernel", "lockstep", "wavefront"])
+def test_light_sum_with_many_nonzero_terms_keeps_the_reference_order(ob, rt, gpu, mode):
+    """reflectType5 adds the pdf terms of ALL lights in list order (material.h:315-323).  The device stores the lights
+    in spatial order and tests only the groups a direction can reach, so it has to put the nonzero terms back into
+    the reference's order: one or two commute, three or more are summed again by selection.  Forty stacked, parallel,
+    overlapping light triangles above a type-5 floor: a direction towards the k-th crosses up to forty of them."""
+    rng = np.random.default_rng(3)
+    recs = []
+    def tri(a, b, c, mat, light=False):
+        r = np.zeros(25, np.float32)
+        r[0:9] = np.concatenate([a, b, c]); n = np.cross(np.subtract(b, a), np.subtract(c, a)); n = n / np.linalg.norm(n)
+        r[9:18] = np.tile(n, 3); r[24] = (1000 if light else 0) + mat + 0.001
+        return r
+    recs.append(tri([-6, -1, 2], [6, -1, 2], [6, -1, -10], 0)); recs.append(tri([-6, -1, 2], [6, -1, -10], [-6, -1, -10], 0))
+    order = rng.permutation(40)                                    # list order is not height order
+    for k in order:
+        y = 0.3 + 0.07 * k; j = rng.uniform(-0.3, 0.3, 2)
+        recs.append(tri([-2 + j[0], y, -1 + j[1]], [0 + j[0], y, -7 + j[1]], [2 + j[0], y, -1 + j[1]], 1, light=True))
+    floor = rt.Material(); floor.type = 5; floor.color = 0xC0C0C0; floor.image_offset[:] = [-1, -1, -1]
+    glow = rt.Material(); glow.type = 1; glow.color = 0xFFFFFF; glow.p1 = 1.5; glow.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(np.stack(recs), [floor, glow])
+    assert sc.desc.n_light_tris == 40
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=6, width=64, height=48, max_bounces=4, flags=rt.F_DEFAULT | rt.F_STATS | rt.MODE_FLAGS[mode])
+    p.cam.pos[:] = [0, 0.1, 1.5]; p.cam.rot[:] = [-0.35, 0, 0]
+    gpu.reset(); st = gpu.render(p); img = gpu.readback()
+    o, ost = ob.render(sc, p, n_threads=8)
+    assert ost.light_tests > 40 * 500                                # the floor is hit and queries the forty lights
+    assert np.array_equal(img, o)
+    assert (st.rays, st.hits, st.light_tests) == (ost.rays, ost.hits, ost.light_tests)
+    if mode == "megakernel":
+        assert st.dev_light_tests != st.light_tests                  # the wave-cooperative loop ran (and the ordered re-sum on top of it)
+
+
 def image_metrics(a, b):
     ya, yb = a @ LUMA, b @ LUMA
     mean_rel = abs(float(ya.mean()) - float(yb.mean())) / float(yb.mean())
