@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1326,8 +1327,20 @@ struct UploadTimer {  // RT_UPLOAD_TIMING=1: wall time of the stages of rt_uploa
 namespace {
 // Everything rt_upload_scene copies to the device, built in host memory (no HIP call): the item stream with the
 // leaf sub-trees, cold triangle data, decoded materials, light records with their group bounds, spheres.
+// A float array that is NOT cleared when it is sized (1.6 GB of zeroes for a 10M-triangle scene, each byte written again
+// right after): whoever sizes it writes every element.
+struct RawFloats {
+    std::unique_ptr<float[]> p;
+    size_t n = 0;
+    void size_to(size_t count) { p.reset(new float[count]); n = count; }
+    float* data() { return p.get(); }
+    const float* data() const { return p.get(); }
+    size_t size() const { return n; }
+    float& operator[](size_t i) { return p[i]; }
+};
 struct HostLayout {
-    std::vector<float> items, cold, mats, lights, spheres;
+    RawFloats items, cold;
+    std::vector<float> mats, lights, spheres;
     std::vector<int> place;  // reference triangle id -> place in the item stream
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
@@ -1439,7 +1452,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
     struct SubWork {  // what one host thread builds: leaves are independent (each reorders its own range of `at`)
         std::vector<SubNode> subs;
-        std::vector<int> sorted;
+        std::vector<int> sorted, best_sorted;
+        std::vector<uint64_t> keys;
         std::vector<float> suffix;
         std::vector<std::pair<int, int>> roots;  // (leaf node, root in subs)
         int deepest = 0;
@@ -1459,11 +1473,19 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             if (n <= sweep_max) {
                 int best_axis = -1, best_k = -1;
                 for (int axis = 0; axis < 3; axis++) {
-                    w.sorted.assign(at.begin() + lo, at.begin() + hi);
-                    std::sort(w.sorted.begin(), w.sorted.end(), [&](int a, int b) {
-                        const float ca = centroid(a, axis), cb = centroid(b, axis);
-                        return ca < cb || (ca == cb && a < b);
-                    });
+                    // by centroid, ties by triangle id: as ONE 64-bit key (the float's bits made monotonic, -0 folded into +0)
+                    w.keys.resize((size_t)n);
+                    for (int p = lo; p < hi; p++) {
+                        const int tri = at[(size_t)p];
+                        const float cc = centroid(tri, axis) + 0.0f;
+                        uint32_t b;
+                        memcpy(&b, &cc, 4);
+                        b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                        w.keys[(size_t)(p - lo)] = ((uint64_t)b << 32) | (uint32_t)tri;
+                    }
+                    std::sort(w.keys.begin(), w.keys.end());
+                    w.sorted.resize((size_t)n);
+                    for (int k = 0; k < n; k++) w.sorted[(size_t)k] = (int)(uint32_t)w.keys[(size_t)k];
                     w.suffix.assign(2 * ((size_t)n + 1), 0.f);  // box area and triangle area of w.sorted[k..n)
                     float bx[6], ar = 0.f;
                     memcpy(bx, kEmpty, sizeof(bx));
@@ -1482,11 +1504,9 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                                           std::min(1.f, w.suffix[2 * (size_t)k] / pa + w.suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
                         if (cst < best) { best = cst; best_axis = axis; best_k = k; }
                     }
+                    if (best_axis == axis) w.best_sorted = w.sorted;  // (this axis holds the best split so far: keep its order)
                 }
-                std::sort(at.begin() + lo, at.begin() + hi, [&](int a, int b) {
-                    const float ca = centroid(a, best_axis), cb = centroid(b, best_axis);
-                    return ca < cb || (ca == cb && a < b);
-                });
+                std::copy(w.best_sorted.begin(), w.best_sorted.end(), at.begin() + lo);
                 mid = lo + best_k;
             } else {
                 float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
@@ -1576,62 +1596,118 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         for (auto& t : th) t.join();
     }
     timer.stage("sub-tree build (threads)");
+    // fn(chunk, lo, hi) over [0, n) cut into n_workers_max ranges, one host thread each (one range when n is small)
+    auto par_ranges = [&](size_t n, auto&& fn) {
+        const int nw = n >= ((size_t)1 << 16) ? n_workers_max : 1;
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < nw; wi++) th.emplace_back([&, wi] { fn(wi, n * (size_t)wi / (size_t)nw, n * (size_t)(wi + 1) / (size_t)nw); });
+        fn(0, (size_t)0, n / (size_t)nw);
+        for (auto& t : th) t.join();
+        return nw;
+    };
     std::vector<SubNode> subs;  // the workers' nodes one after the other (contiguous leaf ranges: same order as one thread's)
     int deepest = max_depth;    // of the whole structure: sizes the traversal stack
-    for (SubWork& w : work) {
-        const int off = (int)subs.size();
-        for (SubNode nd : w.subs) {
-            for (int k = 0; k < 2; k++)
-                if (nd.e[k] >= 0) nd.e[k] += off;
-            subs.push_back(nd);
+    {
+        std::vector<size_t> off((size_t)n_workers + 1, 0);
+        for (int wi = 0; wi < n_workers; wi++) off[(size_t)wi + 1] = off[(size_t)wi] + work[(size_t)wi].subs.size();
+        subs.resize(off[(size_t)n_workers]);
+        auto copy = [&](int wi) {
+            const SubWork& w = work[(size_t)wi];
+            const int o = (int)off[(size_t)wi];
+            for (size_t k = 0; k < w.subs.size(); k++) {
+                SubNode nd = w.subs[k];
+                for (int c = 0; c < 2; c++)
+                    if (nd.e[c] >= 0) nd.e[c] += o;
+                subs[(size_t)o + k] = nd;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < n_workers; wi++) th.emplace_back(copy, wi);
+        copy(0);
+        for (auto& t : th) t.join();
+        for (int wi = 0; wi < n_workers; wi++) {
+            for (const auto& r : work[(size_t)wi].roots) sub_root[(size_t)r.first] = (int)off[(size_t)wi] + r.second;
+            deepest = std::max(deepest, work[(size_t)wi].deepest);
         }
-        for (const auto& r : w.roots) sub_root[(size_t)r.first] = off + r.second;
-        deepest = std::max(deepest, w.deepest);
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
     n_inner = n_top + n_sub;
-    // Item index of every inner node, the reference's and the sub-trees' alike: by box area, biggest first (ties: the
-    // reference's nodes in their order, then the sub-tree nodes in theirs).  A random ray meets a box in proportion to
-    // its area, and the LDS node cache of the kernels holds the items from the front.
+    // Item index of every inner node, the reference's and the sub-trees' alike.  The RT_ITEM_FRONT nodes with the biggest
+    // boxes come first, biggest first (ties: the reference's nodes in their order, then the sub-tree nodes in theirs): a
+    // random ray meets a box in proportion to its area, and the LDS node cache of the kernels holds the items from the
+    // front.  Behind them the reference's BFS order and the sub-trees' depth-first order stay as they are, which keeps
+    // neighbours in the tree close in memory.  "Node q" below: q < nn is the reference's node q, q >= nn sub-tree node q - nn.
     std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0);
     {
         struct Key { float area; int kind, id; };
-        std::vector<Key> keys;
-        keys.reserve((size_t)n_inner);
-        for (int i = 0; i < nn; i++)
-            if (s->nodes[i].child_a != -1) {
-                const float b[6] = {s->nodes[i].bbox_min[0], s->nodes[i].bbox_min[1], s->nodes[i].bbox_min[2],
-                                    s->nodes[i].bbox_max[0], s->nodes[i].bbox_max[1], s->nodes[i].bbox_max[2]};
-                keys.push_back({i == 0 ? 3e38f : half_area(b), 0, i});  // (the root first, whatever its box)
+        auto bigger = [](const Key& a, const Key& b) { return a.area != b.area ? a.area > b.area : (a.kind != b.kind ? a.kind < b.kind : a.id < b.id); };
+        const size_t nq = (size_t)nn + (size_t)n_sub;
+        auto key_of = [&](size_t q, Key& k) -> bool {  // false: a leaf of the reference's tree (no item of its own)
+            if (q < (size_t)nn) {
+                const rt_bvh_node& nd = s->nodes[q];
+                if (nd.child_a == -1) return false;
+                const float b[6] = {nd.bbox_min[0], nd.bbox_min[1], nd.bbox_min[2], nd.bbox_max[0], nd.bbox_max[1], nd.bbox_max[2]};
+                k = {q == 0 ? 3e38f : half_area(b), 0, (int)q};  // (the root first, whatever its box)
+                return true;
             }
-        for (int j = 0; j < n_sub; j++) {
-            const SubNode& nd = subs[(size_t)j];
+            const SubNode& nd = subs[q - (size_t)nn];
             float u[6];
-            for (int k = 0; k < 3; k++) {
-                u[k] = std::min(nd.box[0][k], nd.box[1][k]);
-                u[3 + k] = std::max(nd.box[0][3 + k], nd.box[1][3 + k]);
+            for (int c = 0; c < 3; c++) {
+                u[c] = std::min(nd.box[0][c], nd.box[1][c]);
+                u[3 + c] = std::max(nd.box[0][3 + c], nd.box[1][3 + c]);
             }
-            keys.push_back({half_area(u), 1, j});
-        }
-        // (only the front matters: the RT_ITEM_FRONT biggest, sorted; behind them the reference's BFS order and the
-        // sub-trees' depth-first order stay as they are, which keeps neighbours in the tree close in memory)
-        if (!getenv("RT_ITEMS_BFS")) {  // experiments only: no reordering
-            const size_t front = std::min<size_t>(RT_ITEM_FRONT, keys.size());
-            std::vector<Key> big(keys);
-            auto bigger = [](const Key& a, const Key& b) { return a.area != b.area ? a.area > b.area : (a.kind != b.kind ? a.kind < b.kind : a.id < b.id); };
+            k = {half_area(u), 1, (int)(q - (size_t)nn)};
+            return true;
+        };
+        const size_t front = getenv("RT_ITEMS_BFS") ? 0 : std::min<size_t>(RT_ITEM_FRONT, (size_t)n_inner);  // (RT_ITEMS_BFS: experiments only)
+        // every range keeps its own `front` biggest; the biggest of those are the biggest of all (the order is total)
+        std::vector<std::vector<Key>> top((size_t)n_workers_max);
+        if (front)
+            par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
+                std::vector<Key>& v = top[(size_t)wi];
+                Key k;
+                for (size_t q = lo; q < hi; q++) {
+                    if (!key_of(q, k)) continue;
+                    v.push_back(k);
+                    if (v.size() >= 4 * front) {
+                        std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)front, v.end(), bigger);
+                        v.resize(front);
+                    }
+                }
+            });
+        std::vector<Key> big;
+        for (auto& v : top) big.insert(big.end(), v.begin(), v.end());
+        if (big.size() > front) {
             std::nth_element(big.begin(), big.begin() + (std::ptrdiff_t)front, big.end(), bigger);
             big.resize(front);
-            std::sort(big.begin(), big.end(), bigger);
-            std::vector<char> taken_top((size_t)std::max(nn, 1), 0), taken_sub((size_t)std::max(n_sub, 1), 0);
-            for (const Key& k : big) (k.kind == 0 ? taken_top : taken_sub)[(size_t)k.id] = 1;
-            for (const Key& k : keys)
-                if (!(k.kind == 0 ? taken_top : taken_sub)[(size_t)k.id]) big.push_back(k);
-            keys.swap(big);
         }
-        for (size_t k = 0; k < keys.size(); k++) {
-            if (keys[k].kind == 0) inner_index[(size_t)keys[k].id] = (int)k;
-            else sub_index[(size_t)keys[k].id] = (int)k;
+        std::sort(big.begin(), big.end(), bigger);
+        std::vector<char> taken(std::max<size_t>(nq, 1), 0);
+        for (size_t k = 0; k < big.size(); k++) {
+            const Key& b = big[k];
+            taken[b.kind == 0 ? (size_t)b.id : (size_t)nn + (size_t)b.id] = 1;
+            (b.kind == 0 ? inner_index[(size_t)b.id] : sub_index[(size_t)b.id]) = (int)k;
         }
+        // the others: front + their rank among the nodes not taken (count per range, prefix, assign)
+        std::vector<size_t> cnt((size_t)n_workers_max + 1, 0);
+        const int nr = par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
+            size_t c = 0;
+            for (size_t q = lo; q < hi; q++)
+                if (!taken[q] && (q >= (size_t)nn || s->nodes[q].child_a != -1)) c++;
+            cnt[(size_t)wi + 1] = c;
+        });
+        for (int wi = 0; wi < nr; wi++) cnt[(size_t)wi + 1] += cnt[(size_t)wi];
+        par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
+            size_t k = big.size() + cnt[(size_t)wi];
+            for (size_t q = lo; q < hi; q++) {
+                if (taken[q]) continue;
+                if (q < (size_t)nn) {
+                    if (s->nodes[q].child_a != -1) inner_index[q] = (int)k++;
+                } else {
+                    sub_index[q - (size_t)nn] = (int)k++;
+                }
+            }
+        });
     }
     if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return fail(RT_ERR_LIMIT, "scene too large for 32-bit item indices");
     auto entry_of = [&](int node) -> int {
@@ -1642,60 +1718,61 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         return n_inner + n.tri_offs / RT_TRI_FLOATS;
     };
     timer.stage("merge, order");
-    std::vector<float>& items = L.items;
-    std::vector<float>& cold = L.cold;
+    RawFloats& items = L.items;
+    RawFloats& cold = L.cold;
     std::vector<int>& place = L.place;
-    items.assign(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16, 0.f);
-    cold.assign((size_t)std::max(ntri, 1) * 16, 0.f);
+    items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16);  // (+ one item of padding behind the last triangle)
+    cold.size_to((size_t)std::max(ntri, 1) * 16);
     place.assign((size_t)std::max(ntri, 1), 0);
-    {
-        auto fill = [&](int lo, int hi) {
-            for (int p = lo; p < hi; p++) {
-                const int tri = at[(size_t)p];
-                place[(size_t)tri] = p;
-                const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
-                float* h = &items[((size_t)n_inner + p) * 16];
-                h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
-                h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
-                h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
-                h[9] = i2f((int)tflags[(size_t)p]); h[10] = i2f(leaf_end[(size_t)p]); h[11] = i2f(tri);
-                const float* u = tris + (size_t)p * RT_TRI_FLOATS;             // cold data stays in the reference's order
-                float* cd = &cold[(size_t)p * 16];
-                for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
-                cd[15] = i2f(static_cast<int>(u[24]));  // main.cu:353
-            }
-        };
-        const int nw = ntri >= (1 << 20) ? n_workers_max : 1;
-        std::vector<std::thread> th;
-        for (int wi = 1; wi < nw; wi++) th.emplace_back(fill, (int)((long long)ntri * wi / nw), (int)((long long)ntri * (wi + 1) / nw));
-        fill(0, (int)((long long)ntri / nw));
-        for (auto& t : th) t.join();
-    }
-    for (int i = 0; i < nn; i++) {
-        const rt_bvh_node& n = s->nodes[i];
-        if (n.child_a == -1) continue;
-        float* w = &items[(size_t)inner_index[i] * 16];
-        const rt_bvh_node& A = s->nodes[n.child_a];
-        const rt_bvh_node& B = s->nodes[n.child_b];
-        w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_max[0]; w[3] = A.bbox_max[1];
-        w[4] = B.bbox_min[0]; w[5] = B.bbox_min[1]; w[6] = B.bbox_max[0]; w[7] = B.bbox_max[1];
-        w[8] = A.bbox_min[2]; w[9] = A.bbox_max[2]; w[10] = B.bbox_min[2]; w[11] = B.bbox_max[2];
-        w[12] = i2f(entry_of(n.child_a));
-        w[13] = i2f(entry_of(n.child_b));
-        w[14] = i2f(i);
-        w[15] = 0.f;
-    }
-    for (int j = 0; j < n_sub; j++) {
-        const SubNode& nd = subs[(size_t)j];
-        float* w = &items[(size_t)sub_index[(size_t)j] * 16];
-        const float *A = nd.box[0], *B = nd.box[1];
-        w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
-        w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
-        w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
-        for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? sub_index[(size_t)nd.e[k]] : n_inner + ~nd.e[k]);
-        w[14] = i2f(nd.cnt);
-        w[15] = i2f(1);
-    }
+    for (int k = 0; k < 16; k++) items[((size_t)n_inner + (size_t)ntri) * 16 + (size_t)k] = 0.f;
+    if (ntri == 0)
+        for (int k = 0; k < 16; k++) cold[(size_t)k] = 0.f;
+    par_ranges((size_t)ntri, [&](int, size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; p++) {
+            const int tri = at[p];
+            place[(size_t)tri] = (int)p;
+            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+            float* h = &items[((size_t)n_inner + p) * 16];
+            h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
+            h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
+            h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
+            h[9] = i2f((int)tflags[p]); h[10] = i2f(leaf_end[p]); h[11] = i2f(tri);
+            h[12] = h[13] = h[14] = h[15] = 0.f;
+            const float* u = tris + p * RT_TRI_FLOATS;                    // cold data stays in the reference's order
+            float* cd = &cold[p * 16];
+            for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
+            cd[15] = i2f(static_cast<int>(u[24]));  // main.cu:353
+        }
+    });
+    par_ranges((size_t)nn, [&](int, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const rt_bvh_node& n = s->nodes[i];
+            if (n.child_a == -1) continue;
+            float* w = &items[(size_t)inner_index[i] * 16];
+            const rt_bvh_node& A = s->nodes[n.child_a];
+            const rt_bvh_node& B = s->nodes[n.child_b];
+            w[0] = A.bbox_min[0]; w[1] = A.bbox_min[1]; w[2] = A.bbox_max[0]; w[3] = A.bbox_max[1];
+            w[4] = B.bbox_min[0]; w[5] = B.bbox_min[1]; w[6] = B.bbox_max[0]; w[7] = B.bbox_max[1];
+            w[8] = A.bbox_min[2]; w[9] = A.bbox_max[2]; w[10] = B.bbox_min[2]; w[11] = B.bbox_max[2];
+            w[12] = i2f(entry_of(n.child_a));
+            w[13] = i2f(entry_of(n.child_b));
+            w[14] = i2f((int)i);
+            w[15] = 0.f;
+        }
+    });
+    par_ranges((size_t)n_sub, [&](int, size_t lo, size_t hi) {
+        for (size_t j = lo; j < hi; j++) {
+            const SubNode& nd = subs[j];
+            float* w = &items[(size_t)sub_index[j] * 16];
+            const float *A = nd.box[0], *B = nd.box[1];
+            w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
+            w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
+            w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
+            for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? sub_index[(size_t)nd.e[k]] : n_inner + ~nd.e[k]);
+            w[14] = i2f(nd.cnt);
+            w[15] = i2f(1);
+        }
+    });
 
     timer.stage("item stream, cold data");
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
