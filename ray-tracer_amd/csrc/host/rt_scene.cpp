@@ -23,6 +23,17 @@
 #include <thread>
 #include <vector>
 
+// std::vector<float> whose resize() does not clear: record arrays of a 10M-triangle scene are 1 GB, and every element is
+// written right after the array is sized (value-initialising allocator calls only).
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* ptr) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(ptr)) U; }
+    template <class U, class... A> void construct(U* ptr, A&&... a) { ::new (static_cast<void*>(ptr)) U(std::forward<A>(a)...); }
+};
+using FloatVec = std::vector<float, DefaultInitAlloc<float>>;
+
 namespace {
 
 thread_local std::string g_err;
@@ -405,8 +416,8 @@ void emit_records_to(const ParsedObj& o, const V3& T, float scale, const V3& rot
     }
 }
 
-void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index,
-                  std::vector<float>& out) {
+template <class Vec>
+void emit_records(const ParsedObj& o, const V3& T, float scale, const V3& rot, int material_index, Vec& out) {
     const size_t base = out.size();
     out.resize(base + o.idx.size() / 9 * RT_TRI_FLOATS);
     emit_records_to(o, T, scale, rot, material_index, out.data() + base);
@@ -577,19 +588,30 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             n.b = n.a + 1;
             nodes[n.a].depth = nodes[n.b].depth = n.depth + 1;
         }
+        auto axis_of = [&](const TmpNode& n) {
+            const float xw = n.mx[0] - n.mn[0], yw = n.mx[1] - n.mn[1], zw = n.mx[2] - n.mn[2];
+            if (xw >= yw && xw >= zw) return 0;
+            if (yw >= xw && yw >= zw) return 1;
+            return 2;
+        };
+        // the means of the level's nodes first, one node per thread: a mean is a SERIAL float sum in triangle order (its
+        // rounding is part of the result, :113-123), so the few huge nodes at the top of the tree would otherwise
+        // walk their millions of triangles one node after the other
+        std::vector<float> means(splitting.size());
+        parallel_for(splitting.size(), 1, [&](size_t k) {
+            const TmpNode& n = nodes[splitting[k]];
+            const int axis = axis_of(n);
+            float mean = 0.0f;
+            for (uint32_t i = n.begin; i < n.end; i++) mean += csum[(size_t)ids[i] * 3 + axis];
+            means[k] = mean / static_cast<float>((size_t)(n.end - n.begin) * 3);
+        });
         auto split_one = [&](size_t k) {
             TmpNode& n = nodes[splitting[k]];
             TmpNode& A = nodes[n.a];
             TmpNode& B = nodes[n.b];
-            const float xw = n.mx[0] - n.mn[0], yw = n.mx[1] - n.mn[1], zw = n.mx[2] - n.mn[2];
-            int axis;
-            if (xw >= yw && xw >= zw) axis = 0;
-            else if (yw >= xw && yw >= zw) axis = 1;
-            else axis = 2;
+            const int axis = axis_of(n);
             const uint32_t b = n.begin, e = n.end, cnt = e - b;
-            float mean = 0.0f;  // float accumulation in triangle order, :113-123
-            for (uint32_t i = b; i < e; i++) mean += csum[(size_t)ids[i] * 3 + axis];
-            mean /= static_cast<float>((size_t)cnt * 3);
+            const float mean = means[k];
             // stable partition of ids[b, e): centroid < mean goes to A (:125-135)
             const size_t nchunks = ((size_t)cnt + chunk - 1) / chunk;
             std::vector<uint32_t> na(nchunks + 1, 0);
@@ -809,7 +831,7 @@ struct ASphere { V3 pos; float radius = 0.f; std::string material; };
 
 struct rt_host_scene {
     rt_camera cam{};
-    std::vector<float> tris;  // sphere prefix + records
+    FloatVec tris;  // sphere prefix + records
     int n_spheres = 0;
     std::vector<rt_bvh_node> nodes;
     std::vector<rt_material> mats;
@@ -1012,7 +1034,7 @@ void extract_lights(float* tris, size_t n_floats, std::vector<int32_t>& lights) 
     for (auto& p : part) lights.insert(lights.end(), p.begin(), p.end());  // ascending offsets, like the serial scan
 }
 
-int finish_geometry(rt_host_scene* sc, std::vector<float>& records, int max_depth, int min_tris) {
+int finish_geometry(rt_host_scene* sc, FloatVec& records, int max_depth, int min_tris) {
     // prefix (sphere block) already in sc->tris
     const size_t prefix = sc->tris.size();
     if (prefix == 0) {
@@ -1021,7 +1043,7 @@ int finish_geometry(rt_host_scene* sc, std::vector<float>& records, int max_dept
         sc->tris.resize(prefix + records.size());
         if (!records.empty()) memcpy(sc->tris.data() + prefix, records.data(), records.size() * sizeof(float));
     }
-    std::vector<float>().swap(records);
+    FloatVec().swap(records);
     int rc = build_bvh(sc->tris.data() + prefix, sc->tris.size() - prefix, max_depth, min_tris, sc->nodes, &sc->bvh_depth);
     if (rc != RT_OK) return rc;
     extract_lights(sc->tris.data() + prefix, sc->tris.size() - prefix, sc->lights);
@@ -1288,7 +1310,7 @@ int rt_scene_from_records(const float* tris, size_t n_floats, const rt_material*
     sc->cam.width = 512; sc->cam.height = 512; sc->cam.num_samples = 16;
     sc->cam.focal_length = 1.0f; sc->cam.focus_distance = 4.0f;
     sc->cam.env_width = env_w; sc->cam.env_height = env_h;
-    std::vector<float> rec(tris, tris + n_floats);
+    FloatVec rec(tris, tris + n_floats);
     int rc = finish_geometry(sc, rec, bvh_max_depth, bvh_min_tris);
     if (rc != RT_OK) { delete sc; return rc; }
     sc->mats.assign(mats, mats + n_mats);
@@ -1311,7 +1333,7 @@ int rt_scene_load(const char* scene_path, const char* asset_root, const char* en
 
     // ---- getTriangleData, sceneParser.cpp:398-475 (parsed meshes are cached per model) ----
     std::vector<std::pair<std::string, ParsedObj>> cache;
-    std::vector<float> records;
+    FloatVec records;
     for (const AInstance& in : P.instances) {
         AObject* obj = P.by_name(P.objects, in.object);
         if (!obj) return die("object not found: " + in.object);
@@ -1451,7 +1473,7 @@ int rt_scene_synth_field(const char* obj_path, int instances, uint32_t seed, con
         in.scale = scale * (0.8f + 0.6f * uni());
     }
     const size_t per_inst = po.idx.size() / 9 * RT_TRI_FLOATS;
-    std::vector<float> records;
+    FloatVec records;
     records.reserve((size_t)instances * per_inst + 2 * RT_TRI_FLOATS);
     records.resize((size_t)instances * per_inst);
     StageTimer* tm_emit = new StageTimer("synth: instance records");

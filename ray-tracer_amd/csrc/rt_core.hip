@@ -18,6 +18,7 @@
 //  * raw-sum accumulators + separate resolve kernels (needed for RCCL sum-reduce and progressive batches).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1434,12 +1435,36 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     std::vector<float> tri_area((size_t)std::max(ntri, 1), 0.f);
     double total_area = 0.0;
     float scene_scale = 0.f;  // largest |coordinate| of the scene
-    for (int i = 0; i < ntri; i++) {
-        const float* t = tris + (size_t)i * RT_TRI_FLOATS;
-        for (int k = 0; k < 9; k++) scene_scale = std::max(scene_scale, std::fabs(t[k]));
-        const H3 e1{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
-        tri_area[(size_t)i] = 0.5f * hlen(hcross(e1, e2));
-        total_area += tri_area[(size_t)i];
+    int n_workers_max = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("RT_HOST_THREADS")) n_workers_max = std::min(16, std::max(1, atoi(e)));
+    {   // in fixed chunks of 2^18 triangles whose partial sums are added in chunk order: the same total on any number of threads
+        const size_t chunk = (size_t)1 << 18, nch = ((size_t)ntri + chunk - 1) / chunk;
+        std::vector<double> part_area(std::max<size_t>(nch, 1), 0.0);
+        std::vector<float> part_scale(std::max<size_t>(nch, 1), 0.f);
+        std::atomic<size_t> next{0};
+        auto run = [&] {
+            for (size_t c; (c = next.fetch_add(1)) < nch;) {
+                double a = 0.0;
+                float sc_max = 0.f;
+                for (size_t i = c * chunk; i < std::min((size_t)ntri, (c + 1) * chunk); i++) {
+                    const float* t = tris + i * RT_TRI_FLOATS;
+                    for (int k = 0; k < 9; k++) sc_max = std::max(sc_max, std::fabs(t[k]));
+                    const H3 e1{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+                    tri_area[i] = 0.5f * hlen(hcross(e1, e2));
+                    a += tri_area[i];
+                }
+                part_area[c] = a;
+                part_scale[c] = sc_max;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < (nch > 1 ? n_workers_max : 1); wi++) th.emplace_back(run);
+        run();
+        for (auto& t : th) t.join();
+        for (size_t c = 0; c < nch; c++) {
+            total_area += part_area[c];
+            scene_scale = std::max(scene_scale, part_scale[c]);
+        }
     }
     const float inv_total_area = total_area > 0.0 ? (float)(1.0 / total_area) : 0.f;
     if (!(scene_scale > 0.f) || !(scene_scale < 1e30f)) scene_scale = 1.f;
@@ -1571,8 +1596,6 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
     }
     timer.stage("areas, flags, candidates");
-    int n_workers_max = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("RT_HOST_THREADS")) n_workers_max = std::min(16, std::max(1, atoi(e)));
     const int n_workers = candidates.size() >= 4096 ? n_workers_max : 1;
     std::vector<SubWork> work((size_t)n_workers);
     {
