@@ -67,7 +67,7 @@ def algorithmic_bytes(st, n_pixels):
 def source_sha():
     """Hash of the HIP sources the render kernels are built from: a stored counter file is stale once it changes."""
     h = hashlib.sha256()
-    for f in ("rt_core.hip", "rt_device.h", "rt_pmath.h"):
+    for f in ("rt_core.hip", "rt_device.h", "rt_pmath.h", "rt_pool_kernel.h"):
         with open(os.path.join(ROOT, "ray-tracer_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -103,7 +103,7 @@ def parse_args():
     ap.add_argument("--total-spp", action="store_true", default=None, help="--spp is the job's total: each rank renders spp/N")
     ap.add_argument("--bounces", type=int, default=6)
     ap.add_argument("--partition", choices=["samples", "rows"], default=None)
-    ap.add_argument("--mode", choices=["wavefront", "megakernel", "lockstep"], default="megakernel")
+    ap.add_argument("--mode", choices=["wavefront", "megakernel", "lockstep", "pool"], default="megakernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=None, help="use the synthetic instanced field instead of --scene")
@@ -264,10 +264,11 @@ def main():
             dom_bytes = 56 * st_counts.inner_visits + 8 * st_counts.leaf_visits + 36 * st_counts.tri_tests
             dom_ms = st_prof.trace_ms
             launches = st_prof.trace_launches
-        elif args.mode == "megakernel" and dom_launches > 0:
+        elif args.mode in ("megakernel", "pool") and dom_launches > 0:
             # path-parallel fused kernel: everything but the 12 bytes per pixel of the accumulator update, which
             # rt_sum_samples_kernel does; duration of its launches alone, averaged over the timed steps
-            dom_kernel, dom_bytes = "rt_render_paths_kernel", abytes - 12 * rows * W
+            dom_kernel = "rt_render_pool_kernel" if args.mode == "pool" else "rt_render_paths_kernel"
+            dom_bytes = abytes - 12 * rows * W
             dom_ms, launches = float(np.mean(dom_ms_steps)), dom_launches
         else:
             dom_kernel, dom_bytes, dom_ms, launches = "rt_render_kernel", abytes, k_ms, 1

@@ -125,6 +125,12 @@ enum {
                                    per-path radiance buffer (slower; bit-identical sums) */
     RT_F_WAVEFRONT = 1 << 11,   /* force the wavefront pipeline (logic kernel + persistent trace kernel);
                                    with neither bit the library picks (currently the fused kernel) */
+    RT_F_POOL = 1 << 13,        /* fused path-parallel kernel with the rays regrouped across the 16 waves of a block: some
+                                   waves only walk the tree, the others shade 64 hits / open 64 paths at a time, rays
+                                   change hands through rings in the LDS (rt_pool_kernel.h).  Experimental (slower on the
+                                   bundled scenes, bit-identical sums); plain triangle scenes only -- with RT_F_SPHERES
+                                   and spheres, RT_F_VOLUME, RT_F_RAYMARCH or without RT_F_BVH the ordinary fused
+                                   kernel runs.  Also switched on by the environment variable RT_POOL=1. */
     RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every launch of the dominant kernel (rt_render_stats.trace_ms) */
     RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
 };

@@ -84,8 +84,10 @@ F_MEGAKERNEL = 1 << 9
 F_PROFILE = 1 << 10
 F_WAVEFRONT = 1 << 11
 F_LOCKSTEP = 1 << 12
+F_POOL = 1 << 13
 # the three schedules of the same arithmetic (bit-identical results)
-MODE_FLAGS = {"megakernel": F_MEGAKERNEL, "lockstep": F_MEGAKERNEL | F_LOCKSTEP, "wavefront": F_WAVEFRONT}
+MODE_FLAGS = {"megakernel": F_MEGAKERNEL, "lockstep": F_MEGAKERNEL | F_LOCKSTEP, "wavefront": F_WAVEFRONT,
+              "pool": F_MEGAKERNEL | F_POOL}
 F_DEFAULT = F_SKYBOX | F_ANTIALIAS | F_DEFOCUS | F_BVH
 READ_RAW_SUM, READ_AVERAGE, READ_TONEMAPPED = 0, 1, 2
 (OP_TRI_INTERSECT, OP_AABB_DIST, OP_SPHERE, OP_FLOOR, OP_ITRI_PDF, OP_ITRI_SAMPLE, OP_ATTRACTOR_PDF,

@@ -525,6 +525,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     }
 }
 
+#include "rt_pool_kernel.h"
+
 // Adds the chunk's samples of every pixel, in sample order, to the pixel's running sum of this call (thread = pixel of a
 // tile).  The running sum starts at 0 in the first chunk, is parked in `carry` between chunks and is added to the
 // accumulator after the last one: accum += ((0 + e_0) + e_1) + ... however the call was cut into chunks.
@@ -2106,6 +2108,49 @@ paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop) {
     return table[(stats ? 1 : 0) | (big ? 2 : 0) | (extra ? 4 : 0) | (coop ? 8 : 0)];
 }
 
+// rt_render_pool_kernel (rt_pool_kernel.h): n_trav traversal waves with stacks, the others shade; the rings' bytes come
+// out of the stacks the vertex waves do not need and, beyond that, out of the node cache.
+struct PoolCfg {
+    int n_trav, cap_ready, cap_hit, cap_miss, population, n_cached, n_mats_lds, stack_entries;
+    size_t lds_bytes;
+};
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int pow2_floor(int v) {
+    int p = 1;
+    while (p * 2 <= v) p *= 2;
+    return p;
+}
+PoolCfg pool_cfg(rt_context* c) {
+    PoolCfg p;
+    p.n_trav = std::min(RT_MEGA_WAVES - 1, std::max(1, env_int("RT_POOL_TRAV", 12)));
+    p.cap_ready = pow2_floor(std::max(64, env_int("RT_POOL_READY", 256)));
+    p.cap_hit = pow2_floor(std::max(64, env_int("RT_POOL_HIT", 128)));
+    p.cap_miss = pow2_floor(std::max(64, env_int("RT_POOL_MISS", 128)));
+    const int max_surplus = p.cap_ready + std::min(p.cap_hit, p.cap_miss) - 64;
+    p.population = p.n_trav * 64 + std::min(max_surplus, std::max(64, env_int("RT_POOL_SURPLUS", 320)));
+    p.stack_entries = std::max(c->bvh_depth, 1);
+    p.n_mats_lds = (c->sc.n_mats <= RT_LDS_MATS_MAX) ? c->sc.n_mats : 0;
+    const size_t fixed = (size_t)p.n_trav * p.stack_entries * 256 + (size_t)p.n_mats_lds * 48 + (size_t)p.cap_ready * 16 * RT_POOL_READY_F4 +
+                         (size_t)p.cap_hit * 16 * RT_POOL_HIT_F4 + (size_t)p.cap_miss * 16 * RT_POOL_MISS_F4 + 16 * RT_POOL_CTL_F4;
+    const size_t budget = 160 * 1024 - 1024;
+    size_t cache_nodes = budget > fixed ? (budget - fixed) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
+    if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
+    p.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)c->sc.n_inner);
+    p.lds_bytes = RT_LDS_CACHE_FLOAT4S(p.n_cached) * 16 + fixed;
+    return p;
+}
+typedef void (*pool_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int, int, int, int, int, int, int);
+pool_fn pool_kernel_variant(bool stats, bool big, bool coop) {
+    static const pool_fn table[8] = {rt_render_pool_kernel<false, false, false>, rt_render_pool_kernel<true, false, false>,
+                                     rt_render_pool_kernel<false, true, false>,  rt_render_pool_kernel<true, true, false>,
+                                     rt_render_pool_kernel<false, false, true>,  rt_render_pool_kernel<true, false, true>,
+                                     rt_render_pool_kernel<false, true, true>,   rt_render_pool_kernel<true, true, true>};
+    return table[(stats ? 1 : 0) | (big ? 2 : 0) | (coop ? 4 : 0)];
+}
+
 int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
@@ -2113,6 +2158,9 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     for (int v = 0; v < 16; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    for (int v = 0; v < 8; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)pool_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     c->mega_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
@@ -2165,11 +2213,18 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
                                             c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
+    // the block-level ray pool (RT_F_POOL / RT_POOL=1): plain triangle scenes (no spheres, volume, ray marching, brute force)
+    const bool pool_wanted = (P.flags & RT_F_POOL) || (getenv("RT_POOL") && atoi(getenv("RT_POOL")) != 0);
+    const bool pool = pool_wanted && !(P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) && (P.flags & RT_F_BVH) &&
+                      !((P.flags & RT_F_SPHERES) && c->sc.n_spheres > 0);
+    const PoolCfg pc = pool ? pool_cfg(c) : PoolCfg();
+    const pool_fn pfn = pool_kernel_variant(want_stats, c->sc.n_sub > 0, c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
+    if (pool) occ = 1;
     size_t ev_used = 0;
     for (long long k0 = 0; k0 < P.sample_count; k0 += S) {
         const int s = (int)std::min<long long>(S, P.sample_count - k0);
         const unsigned int n_paths = (unsigned int)(slots * (size_t)s);
-        HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, sizeof(unsigned int), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_tile_counter, 0, (pool ? 3 : 1) * sizeof(unsigned int), c->stream));  // ([2]: the pool kernel's give-up flag)
         const long long want_blocks = ((long long)n_paths + 64 * RT_MEGA_WAVES - 1) / (64 * RT_MEGA_WAVES);
         const int blocks = (int)std::max<long long>(1, std::min<long long>((long long)c->num_cus * occ, want_blocks));
         const bool timed = profile && ev_used + 2 <= 4096;
@@ -2181,8 +2236,13 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
             }
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used], c->stream));
         }
-        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, c->d_samples, c->d_tile_counter,
-                           c->d_stats, tc.n_cached, tc.stack_entries, (int)k0, s, n_paths, tc.n_mats_lds);
+        if (pool)
+            hipLaunchKernelGGL(pfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), pc.lds_bytes, c->stream, c->sc, P, c->d_samples, c->d_tile_counter,
+                               c->d_stats, pc.n_cached, pc.stack_entries, (int)k0, s, n_paths, pc.n_mats_lds, pc.n_trav, pc.cap_ready,
+                               pc.cap_hit, pc.cap_miss, pc.population);
+        else
+            hipLaunchKernelGGL(kfn, dim3(blocks), dim3(64 * RT_MEGA_WAVES), tc.lds_bytes, c->stream, c->sc, P, c->d_samples, c->d_tile_counter,
+                               c->d_stats, tc.n_cached, tc.stack_entries, (int)k0, s, n_paths, tc.n_mats_lds);
         if (timed) {
             HIP_TRY(c, hipEventRecord(c->ev_pool[ev_used + 1], c->stream));
             ev_used += 2;
@@ -2191,6 +2251,11 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
                            c->d_samples + slots * (size_t)S * 3, P, s, (int)(k0 == 0), (int)(k0 + s >= P.sample_count));
     }
     HIP_TRY(c, hipGetLastError());
+    if (pool) {  // a wave that waited for seconds gave up (rt_pool_kernel.h): the sums are incomplete
+        HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_tile_counter + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_pinned[0] != 0) return set_err(c, RT_ERR_DEVICE, "the ray pool kernel gave up waiting (watchdog)");
+    }
     if (out && profile && ev_used) {  // RT_F_PROFILE: summed duration of the path kernel's launches alone
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         double sum = 0.0;
@@ -2322,6 +2387,14 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
         if (want_stats) {
             unsigned long long h[32];
             HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+#ifdef RT_POOL_CENSUS
+            if (h[16])
+                fprintf(stderr, "[rt pool] traversal waves: %llu iterations, lanes walking %.1f / finished %.1f / empty %.1f; exchanges in %.3f of them, %.1f rays taken each; "
+                                "%llu idle polls; leaf iterations %.3f (%.1f lanes at a leaf).  vertex waves: %llu idle polls, %llu shade jobs of %.1f, %llu close/open jobs of %.1f + %.1f\n",
+                        h[16], (double)h[17] / h[16], (double)h[18] / h[16], (double)h[19] / h[16], (double)h[20] / h[16], h[20] ? (double)h[21] / h[20] : 0.0, h[22],
+                        (double)h[23] / h[16], h[23] ? (double)h[24] / h[23] : 0.0, h[25], h[26], h[26] ? (double)h[27] / h[26] : 0.0, h[28],
+                        h[28] ? (double)h[29] / h[28] : 0.0, h[28] ? (double)h[30] / h[28] : 0.0);
+#endif
 #ifdef RT_CYCLE_PROF
             fprintf(stderr, "[rt prof] trav: %llu wave-iterations, %llu lane-steps (%.1f lanes/iteration), %llu cycles (%.0f per iteration); "
                             "vertex: %llu passes, %llu lanes (%.1f per pass), %llu cycles (%.0f per pass)(shading part %.0f); wave lifetimes %llu cycles; kernel %.3f ms\n",

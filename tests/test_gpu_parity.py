@@ -168,7 +168,7 @@ def test_random_scenes_all_schedules_match_oracle(ob, rt, gpu, seed, monkeypatch
     p.seed = int(rng.integers(0, 1 << 31))
     p.sample_begin = int(rng.integers(0, 1000))
     o, ost = ob.render(sc, p, n_threads=8)
-    for mode in ("megakernel", "lockstep", "wavefront"):
+    for mode in ("megakernel", "lockstep", "wavefront", "pool"):
         q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
         gpu.reset(); st = gpu.render(q)
         assert np.array_equal(gpu.readback(), o), (seed, mode)
@@ -191,7 +191,7 @@ def test_light_loop_over_several_chunks(ob, rt, gpu, n, frac):
     p = rt.default_params(sc.camera, spp=4, width=96, height=80, max_bounces=5, flags=rt.F_BVH | rt.F_STATS)
     p.seed = 5
     o, ost = ob.render(sc, p, n_threads=8)
-    for mode in ("megakernel", "lockstep"):
+    for mode in ("megakernel", "lockstep", "pool"):
         q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
         gpu.reset(); st = gpu.render(q)
         assert np.array_equal(gpu.readback(), o), mode
@@ -239,7 +239,7 @@ def image_metrics(a, b):
     return mean_rel, rel_rmse
 
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep", "pool"])
 @pytest.mark.parametrize("name,size,spp,bounces", [
     ("scene_cornellbox.txt", 256, 16, 4),   # BASELINE config 1 (reduced image size elsewhere)
     ("scene.txt", 128, 16, 6),
