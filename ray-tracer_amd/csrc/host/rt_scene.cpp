@@ -475,11 +475,13 @@ struct TmpNode {
     uint32_t begin = 0, end = 0;  // its triangles: ids[begin, end), input order preserved
     int a = -1, b = -1;
     int depth = 0;
+    float sum3[3] = {0.f, 0.f, 0.f};  // per axis, the serial float sum of its triangles' vertex sums in triangle order ...
+    bool has_sum = false;             // ... when the pass that made the node formed it on the way
 };
 
 // Output stage shared by the builders: nodes are in creation order = BFS order, A before B (BFSIndex,
 // BVHcreator.cpp:41-61); triangles are rewritten leaf by leaf in that order (populateBVHNodes :209-237).
-int finish_bvh(const std::vector<TmpNode>& nodes, const std::vector<uint32_t>& ids, float* tris, size_t n_floats,
+int finish_bvh(const std::vector<TmpNode>& nodes, const uint32_t* ids, float* tris, size_t n_floats,
                std::vector<rt_bvh_node>& out, int* out_depth) {
     StageTimer tm_out("bvh: numbering + reorder");
     out.resize(nodes.size());
@@ -527,10 +529,18 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
     if (n_floats % RT_TRI_FLOATS != 0) return fail("triangle array length is not a multiple of 25");
     const size_t ntri = n_floats / RT_TRI_FLOATS;
     if (ntri > 0x7fffffffu / RT_TRI_FLOATS) return fail("too many triangles for int32 float offsets");
-    size_t chunk = (size_t)1 << 18;  // triangles per parallel chunk of a big node (RT_BVH_CHUNK: tests force small chunks)
-    if (const char* e = getenv("RT_BVH_CHUNK")) chunk = (size_t)std::max(1, atoi(e));
-    std::vector<float> csum(ntri * 3), tbox(ntri * 6);
-    std::vector<uint32_t> ids(ntri), tmp(ntri);
+    size_t chunk_max = (size_t)1 << 18;  // triangles per parallel chunk of a big node, at most (RT_BVH_CHUNK: tests force small chunks)
+    if (const char* e = getenv("RT_BVH_CHUNK")) chunk_max = (size_t)std::max(1, atoi(e));
+    const size_t small_node = std::min<size_t>(chunk_max, (size_t)1 << 16);  // levels of nodes this small never use the chunked path
+    const bool force_single_pass = getenv("RT_BVH_SINGLE_PASS") != nullptr;  // (tests: both paths on the same input)
+    const size_t chunk = chunk_max;        // (range_box below: chunk of the fold)
+    // (none of these is zero-filled: every element is written before it is read)
+    std::unique_ptr<float[]> csum_mem(new float[std::max<size_t>(ntri, 1) * 3]), tbox_mem(new float[std::max<size_t>(ntri, 1) * 6]);
+    float* csum = csum_mem.get();
+    float* tbox = tbox_mem.get();
+    std::unique_ptr<uint32_t[]> ids_mem(new uint32_t[std::max<size_t>(ntri, 1)]), tmp_mem(new uint32_t[std::max<size_t>(ntri, 1)]);
+    uint32_t* ids = ids_mem.get();
+    uint32_t* tmp = tmp_mem.get();
     std::vector<TmpNode> nodes(1);
     {
         StageTimer tm("bvh: per-triangle sums, boxes");
@@ -550,14 +560,13 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
         const size_t n = e - b, nchunks = (n + chunk - 1) / chunk;
         std::vector<float> part(std::max<size_t>(nchunks, 1) * 6);
         auto fold = [&](size_t k) {
-            float* p = &part[k * 6];
-            p[0] = p[1] = p[2] = 1e12f;
-            p[3] = p[4] = p[5] = -1e12f;
+            float p[6] = {1e12f, 1e12f, 1e12f, -1e12f, -1e12f, -1e12f};  // (local: the chunks' results share cache lines)
             const size_t lo = b + k * chunk, hi = std::min<size_t>(e, lo + chunk);
             for (size_t i = lo; i < hi; i++) {
                 const float* bx = &tbox[(size_t)ids[i] * 6];
                 for (int c = 0; c < 3; c++) { p[c] = fminf(p[c], bx[c]); p[3 + c] = fmaxf(p[3 + c], bx[3 + c]); }
             }
+            memcpy(&part[k * 6], p, sizeof(p));
         };
         if (nchunks > 1) parallel_for(nchunks, 1, fold);
         else fold(0);
@@ -569,6 +578,10 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
     nodes[0].end = (uint32_t)ntri;
     range_box(0, (uint32_t)ntri, nodes[0].mn, nodes[0].mx);
 
+    bool regrouped = false;
+    std::unique_ptr<uint32_t[]> orig_mem;
+    size_t regroup_below = (size_t)1 << 17;
+    if (const char* e = getenv("RT_BVH_REGROUP")) regroup_below = (size_t)std::max(0, atoi(e));  // (0: never; tests: other thresholds)
     StageTimer* tm_split = new StageTimer("bvh: splits");
     std::vector<int> level{0}, splitting;
     int deepest_leaf = 0;
@@ -580,6 +593,7 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             if (n.depth >= max_depth || (int)cnt <= min_tris || cnt <= 2) { deepest_leaf = std::max(deepest_leaf, n.depth); continue; }
             splitting.push_back(ni);
         }
+        const auto lvl_t0 = std::chrono::steady_clock::now();
         const size_t first_child = nodes.size();
         nodes.resize(first_child + 2 * splitting.size());
         for (size_t k = 0; k < splitting.size(); k++) {
@@ -602,9 +616,38 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             const TmpNode& n = nodes[splitting[k]];
             const int axis = axis_of(n);
             float mean = 0.0f;
-            for (uint32_t i = n.begin; i < n.end; i++) mean += csum[(size_t)ids[i] * 3 + axis];
+            if (n.has_sum) mean = n.sum3[axis];  // (the same additions in the same order, made while the node was filled)
+            else for (uint32_t i = n.begin; i < n.end; i++) mean += csum[(size_t)ids[i] * 3 + axis];
             means[k] = mean / static_cast<float>((size_t)(n.end - n.begin) * 3);
         });
+        const double lvl_means_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lvl_t0).count();
+        // few nodes (the top of the tree): one after the other, each shared by the threads in chunks; enough nodes to go
+        // round (or nothing big among them): one node per task, split by its thread in a single pass
+        size_t biggest = 0;
+        for (int ni : splitting) biggest = std::max<size_t>(biggest, nodes[ni].end - nodes[ni].begin);
+        const bool node_per_task = splitting.size() >= (size_t)host_threads() * 2 || biggest <= small_node || force_single_pass;
+        if (!regrouped && biggest <= regroup_below && !splitting.empty()) {
+            // once the nodes are small: the per-triangle sums and boxes rewritten in the order of the id array, so that a
+            // node's data is one contiguous piece (a few MB at most) instead of a gather over its whole instance; from here
+            // on the id array holds POSITIONS in that copy and `orig` leads back to the triangles
+            regrouped = true;
+            std::unique_ptr<float[]> csum2(new float[ntri * 3]), tbox2(new float[ntri * 6]);
+            orig_mem.reset(new uint32_t[ntri]);
+            uint32_t* orig = orig_mem.get();
+            float* c2 = csum2.get();
+            float* b2 = tbox2.get();
+            parallel_for(ntri, 1 << 16, [&](size_t j) {
+                const uint32_t t = ids[j];
+                memcpy(&c2[j * 3], &csum[(size_t)t * 3], 3 * sizeof(float));
+                memcpy(&b2[j * 6], &tbox[(size_t)t * 6], 6 * sizeof(float));
+                orig[j] = t;
+                ids[j] = (uint32_t)j;
+            });
+            csum_mem.swap(csum2);
+            tbox_mem.swap(tbox2);
+            csum = csum_mem.get();
+            tbox = tbox_mem.get();
+        }
         auto split_one = [&](size_t k) {
             TmpNode& n = nodes[splitting[k]];
             TmpNode& A = nodes[n.a];
@@ -612,7 +655,37 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             const int axis = axis_of(n);
             const uint32_t b = n.begin, e = n.end, cnt = e - b;
             const float mean = means[k];
-            // stable partition of ids[b, e): centroid < mean goes to A (:125-135)
+            if (node_per_task) {
+                // one pass: A's ids move forward in place (never past the read position), B's wait in tmp; the children's
+                // boxes and their three serial sums (the next level's means, whichever axis it picks) are formed on the way
+                float amn[3] = {1e12f, 1e12f, 1e12f}, amx[3] = {-1e12f, -1e12f, -1e12f};
+                float bmn[3] = {1e12f, 1e12f, 1e12f}, bmx[3] = {-1e12f, -1e12f, -1e12f};
+                float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+                uint32_t pa = b, pb = b;
+                for (uint32_t i = b; i < e; i++) {
+                    const uint32_t t = ids[i];
+                    const float* cs = &csum[(size_t)t * 3];
+                    const float* bx = &tbox[(size_t)t * 6];
+                    if (cs[axis] / 3.0f < mean) {
+                        ids[pa++] = t;
+                        for (int c = 0; c < 3; c++) { sa[c] += cs[c]; amn[c] = fminf(amn[c], bx[c]); amx[c] = fmaxf(amx[c], bx[3 + c]); }
+                    } else {
+                        tmp[pb++] = t;
+                        for (int c = 0; c < 3; c++) { sb[c] += cs[c]; bmn[c] = fminf(bmn[c], bx[c]); bmx[c] = fmaxf(bmx[c], bx[3 + c]); }
+                    }
+                }
+                memcpy(&ids[pa], &tmp[b], (size_t)(pb - b) * sizeof(uint32_t));
+                A.begin = b; A.end = pa;
+                B.begin = pa; B.end = e;
+                for (int c = 0; c < 3; c++) {
+                    A.mn[c] = amn[c]; A.mx[c] = amx[c]; A.sum3[c] = sa[c];
+                    B.mn[c] = bmn[c]; B.mx[c] = bmx[c]; B.sum3[c] = sb[c];
+                }
+                A.has_sum = B.has_sum = true;
+                return;
+            }
+            // a big node: the threads share it.  Stable partition of ids[b, e): centroid < mean goes to A (:125-135)
+            const size_t chunk = std::min(chunk_max, std::max<size_t>((size_t)1 << 14, (size_t)cnt / ((size_t)host_threads() * 4)));
             const size_t nchunks = ((size_t)cnt + chunk - 1) / chunk;
             std::vector<uint32_t> na(nchunks + 1, 0);
             auto count = [&](size_t c) {
@@ -625,30 +698,51 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             else count(0);
             for (size_t c = 0; c < nchunks; c++) na[c + 1] += na[c];
             const uint32_t total_a = na[nchunks];
+            std::vector<float> part(nchunks * 12);  // per chunk: box of its A part, box of its B part (min / max are exact: any grouping)
             auto scatter = [&](size_t c) {
                 const size_t lo = b + c * chunk, hi = std::min<size_t>(e, lo + chunk);
                 uint32_t pa = b + na[c], pb = b + total_a + (uint32_t)(lo - b) - na[c];
+                float bb[12] = {1e12f, 1e12f, 1e12f, -1e12f, -1e12f, -1e12f, 1e12f, 1e12f, 1e12f, -1e12f, -1e12f, -1e12f};
                 for (size_t i = lo; i < hi; i++) {
                     const uint32_t t = ids[i];
-                    if (csum[(size_t)t * 3 + axis] / 3.0f < mean) tmp[pa++] = t;
-                    else tmp[pb++] = t;
+                    const float* bx = &tbox[(size_t)t * 6];
+                    float* q;
+                    if (csum[(size_t)t * 3 + axis] / 3.0f < mean) { tmp[pa++] = t; q = bb; }
+                    else { tmp[pb++] = t; q = bb + 6; }
+                    for (int d = 0; d < 3; d++) { q[d] = fminf(q[d], bx[d]); q[3 + d] = fmaxf(q[3 + d], bx[3 + d]); }
                 }
+                memcpy(&part[c * 12], bb, sizeof(bb));
             };
             if (nchunks > 1) parallel_for(nchunks, 1, scatter);
             else scatter(0);
-            memcpy(&ids[b], &tmp[b], (size_t)cnt * sizeof(uint32_t));
+            auto copy_back = [&](size_t c) {
+                const size_t lo = b + c * chunk, hi = std::min<size_t>(e, lo + chunk);
+                memcpy(&ids[lo], &tmp[lo], (hi - lo) * sizeof(uint32_t));
+            };
+            if (nchunks > 1) parallel_for(nchunks, 1, copy_back);
+            else copy_back(0);
             A.begin = b; A.end = b + total_a;
             B.begin = b + total_a; B.end = e;
-            range_box(A.begin, A.end, A.mn, A.mx);
-            range_box(B.begin, B.end, B.mn, B.mx);
+            for (int d = 0; d < 3; d++) { A.mn[d] = B.mn[d] = 1e12f; A.mx[d] = B.mx[d] = -1e12f; }
+            for (size_t c = 0; c < nchunks; c++)
+                for (int d = 0; d < 3; d++) {
+                    A.mn[d] = fminf(A.mn[d], part[c * 12 + d]);     A.mx[d] = fmaxf(A.mx[d], part[c * 12 + 3 + d]);
+                    B.mn[d] = fminf(B.mn[d], part[c * 12 + 6 + d]); B.mx[d] = fmaxf(B.mx[d], part[c * 12 + 9 + d]);
+                }
         };
-        // few big nodes: one after the other, each using the threads inside; many small nodes: one node per task
-        if (splitting.size() < (size_t)host_threads() * 2) for (size_t k = 0; k < splitting.size(); k++) split_one(k);
+        if (!node_per_task) for (size_t k = 0; k < splitting.size(); k++) split_one(k);
         else parallel_for(splitting.size(), 1, split_one);
         level.clear();
         for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
+        if (getenv("RT_SCENE_TIMING") && atoi(getenv("RT_SCENE_TIMING")) >= 2)
+            fprintf(stderr, "[rt_scene]   level of %zu splitting nodes: %.1f ms (means %.1f)\n", splitting.size(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lvl_t0).count(), lvl_means_ms);
     }
     delete tm_split;
+    if (regrouped) {
+        const uint32_t* orig = orig_mem.get();
+        parallel_for(ntri, 1 << 16, [&](size_t j) { ids[j] = orig[ids[j]]; });
+    }
     return finish_bvh(nodes, ids, tris, n_floats, out, out_depth);
 }
 
@@ -795,7 +889,7 @@ int build_bvh_sah(float* tris, size_t n_floats, int max_depth, int leaf_tris, st
         level.clear();
         for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
     }
-    return finish_bvh(nodes, ids, tris, n_floats, out, out_depth);
+    return finish_bvh(nodes, ids.data(), tris, n_floats, out, out_depth);
 }
 
 // ------------------------------------------------------------------ scene DSL

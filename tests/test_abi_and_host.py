@@ -286,6 +286,29 @@ def test_bvh_parallel_chunks_change_nothing(rt, monkeypatch, chunk):
     assert got_nodes == ref_nodes and np.array_equal(got_tris, ref_tris)
 
 
+@pytest.mark.parametrize("env", [{"RT_BVH_SINGLE_PASS": "1"}, {"RT_BVH_REGROUP": "0"}, {"RT_BVH_REGROUP": "40"},
+                                 {"RT_BVH_REGROUP": "1000000000"}, {"RT_BVH_REGROUP": "300", "RT_BVH_CHUNK": "5"},
+                                 {"RT_BVH_SINGLE_PASS": "1", "RT_BVH_REGROUP": "100"}])
+def test_bvh_builder_paths_change_nothing(rt, monkeypatch, env):
+    """The builder's three ways through a level -- a big node shared by the threads in chunks (boxes folded per chunk), one
+    node per task split in a single pass (children's boxes and serial sums formed on the way), and either of them after
+    the per-triangle data has been regrouped into id-array order -- give the nodes, boxes and triangle order of the
+    Python restatement of BVHcreator.cpp, wherever the switch-over points are put."""
+    for n, seed in ((600, 4), (5000, 9)):
+        tris = random_soup(n, seed)
+        exp_nodes, exp_tris = py_bvh(tris)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got_nodes, got_tris = build(rt, tris)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert len(got_nodes) == len(exp_nodes)
+        for g, e in zip(got_nodes, exp_nodes):
+            assert g[2:] == e[2:]
+            assert np.array_equal(np.float32(g[0]), np.float32(e[0])) and np.array_equal(np.float32(g[1]), np.float32(e[1]))
+        assert np.array_equal(got_tris, exp_tris)
+
+
 def test_bvh_cornell_matches_python_restatement(rt, scenes):
     # rebuild from the (already reordered) cornell records: same records -> same tree shape
     s = scenes("scene_cornellbox.txt")
