@@ -1477,16 +1477,146 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     // as the reference does.
     const float box_pad = 1e-5f * scene_scale;
     const float kEmpty[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+    const bool getenv_old_sweep = getenv("RT_SUB_RESORT") != nullptr;  // (tests: the sort-at-every-node form of the sweep, same result)
     struct SubWork {  // what one host thread builds: leaves are independent (each reorders its own range of `at`)
         std::vector<SubNode> subs;
         std::vector<int> sorted, best_sorted;
         std::vector<uint64_t> keys;
+        // sweep_sub: the node of at most sweep_max triangles being built: its triangles, their boxes and areas, and per
+        // axis the local indices in sorted order (position p of `at` <-> entry p - base)
+        int base = 0;
+        std::vector<int> ltri, ord[3], scratch;
+        std::vector<float> lbox, larea;
+        std::vector<unsigned char> side;
         std::vector<float> suffix;
         std::vector<std::pair<int, int>> roots;  // (leaf node, root in subs)
         int deepest = 0;
     };
+    // The sweep builder below a node of at most sweep_max triangles.  Its triangles are sorted ONCE per axis (by centroid,
+    // ties by triangle id: as one 64-bit key, the float's bits made monotonic, -0 folded into +0); a split keeps the
+    // three orders by stable partition, so a child's orders are what sorting the child would give (the keys are
+    // distinct) -- the same splits, leaves and triangle order as sorting at every node, without the sorting.
+    // Per-triangle centroids are not needed after the sort; boxes and areas sit in small local arrays.
+    auto sweep_sub = [&](auto&& self, SubWork& w, int lo, int hi, int d, float* box, bool root) -> int {
+        const int n = hi - lo, o = lo - w.base;
+        float tight[6];
+        memcpy(tight, kEmpty, sizeof(tight));
+        for (int k = 0; k < n; k++) {
+            const float* b = &w.lbox[6 * (size_t)w.ord[0][(size_t)(o + k)]];
+            for (int c = 0; c < 3; c++) { tight[c] = std::min(tight[c], b[c]); tight[3 + c] = std::max(tight[3 + c], b[3 + c]); }
+        }
+        memcpy(box, tight, sizeof(tight));
+        for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
+        w.deepest = std::max(w.deepest, d);
+        int mid = -1;
+        const float pa = half_area(tight);
+        if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
+            float best = 3e38f;  // expected triangle tests below this node if it is split
+            int best_axis = -1, best_k = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                const int* so = &w.ord[axis][(size_t)o];
+                float bx[6], ar = 0.f;
+                memcpy(bx, kEmpty, sizeof(bx));
+                for (int k = n - 1; k >= 1; k--) {  // box area and triangle area of so[k..n)
+                    const float* b = &w.lbox[6 * (size_t)so[k]];
+                    for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], b[c]); bx[3 + c] = std::max(bx[3 + c], b[3 + c]); }
+                    ar += w.larea[(size_t)so[k]];
+                    w.suffix[2 * (size_t)k] = half_area(bx);
+                    w.suffix[2 * (size_t)k + 1] = ar;
+                }
+                memcpy(bx, kEmpty, sizeof(bx));
+                ar = 0.f;
+                for (int k = 1; k < n; k++) {  // left = the first k
+                    const float* b = &w.lbox[6 * (size_t)so[k - 1]];
+                    for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], b[c]); bx[3 + c] = std::max(bx[3 + c], b[3 + c]); }
+                    ar += w.larea[(size_t)so[k - 1]];
+                    const float cst = std::min(1.f, half_area(bx) / pa + ar * inv_total_area) * (float)k +
+                                      std::min(1.f, w.suffix[2 * (size_t)k] / pa + w.suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
+                    if (cst < best) { best = cst; best_axis = axis; best_k = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int* so = &w.ord[best_axis][(size_t)o];
+                for (int k = 0; k < n; k++) at[(size_t)(lo + k)] = w.ltri[(size_t)so[k]];  // the node's triangles in the order of the best axis
+                mid = lo + best_k;
+                // walk n triangles, or one more node and the triangles of the children that are reached
+                if (n <= RT_SUB_LEAF_MAX && !(cost_inner + best < gain * (float)n)) mid = -1;
+                if (mid >= 0) {
+                    for (int k = 0; k < n; k++) w.side[(size_t)so[k]] = (unsigned char)(k < best_k ? 1 : 0);
+                    for (int axis = 0; axis < 3; axis++) {
+                        if (axis == best_axis) continue;
+                        int* oa = &w.ord[axis][(size_t)o];
+                        int nl = 0, nr = 0;
+                        for (int k = 0; k < n; k++) {
+                            const int t = oa[k];
+                            if (w.side[(size_t)t]) oa[nl++] = t;      // (never past the read position)
+                            else w.scratch[(size_t)nr++] = t;
+                        }
+                        memcpy(oa + nl, w.scratch.data(), (size_t)nr * sizeof(int));
+                    }
+                }
+            }
+        }
+        if (mid < 0) {
+            if (root) {
+                std::sort(at.begin() + lo, at.begin() + hi);
+                return -1 - 0x40000000;
+            }
+            for (int p = lo; p < hi; p++) tflags[(size_t)p] = (unsigned char)(4 | (p == hi - 1 ? 1 : 0));
+            return ~lo;
+        }
+        const int idx = (int)w.subs.size();
+        w.subs.push_back(SubNode());
+        float ba[6], bb[6];
+        const int ea = self(self, w, lo, mid, d + 1, ba, false), eb = self(self, w, mid, hi, d + 1, bb, false);
+        SubNode& nd = w.subs[(size_t)idx];
+        memcpy(nd.box[0], ba, sizeof(ba));
+        memcpy(nd.box[1], bb, sizeof(bb));
+        nd.e[0] = ea;
+        nd.e[1] = eb;
+        nd.cnt = 0;
+        return idx;
+    };
+    auto sweep_begin = [&](SubWork& w, int lo, int hi) {  // local copies and the three sorted orders of at[lo, hi)
+        const int n = hi - lo;
+        w.base = lo;
+        w.ltri.resize((size_t)n);
+        w.lbox.resize(6 * (size_t)n);
+        w.larea.resize((size_t)n);
+        w.side.resize((size_t)n);
+        w.scratch.resize((size_t)n);
+        w.suffix.resize(2 * ((size_t)n + 1));
+        w.keys.resize((size_t)n);
+        for (int k = 0; k < n; k++) w.ltri[(size_t)k] = at[(size_t)(lo + k)];
+        // local indices in triangle-id order (they already are below a reference leaf): the index then breaks ties like the id
+        if (!std::is_sorted(w.ltri.begin(), w.ltri.end())) std::sort(w.ltri.begin(), w.ltri.end());
+        for (int k = 0; k < n; k++) {
+            const int tri = w.ltri[(size_t)k];
+            float* b = &w.lbox[6 * (size_t)k];
+            memcpy(b, kEmpty, 6 * sizeof(float));
+            grow(b, tri);
+            w.larea[(size_t)k] = tri_area[(size_t)tri];
+        }
+        for (int axis = 0; axis < 3; axis++) {
+            for (int k = 0; k < n; k++) {
+                const int tri = w.ltri[(size_t)k];
+                const float cc = centroid(tri, axis) + 0.0f;
+                uint32_t b;
+                memcpy(&b, &cc, 4);
+                b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                w.keys[(size_t)k] = ((uint64_t)b << 32) | (uint32_t)k;
+            }
+            std::sort(w.keys.begin(), w.keys.end());
+            w.ord[axis].resize((size_t)n);
+            for (int k = 0; k < n; k++) w.ord[axis][(size_t)k] = (int)(uint32_t)w.keys[(size_t)k];
+        }
+    };
     auto build_sub = [&](auto&& self, SubWork& w, int lo, int hi, int d, float* box, bool root) -> int {
         const int n = hi - lo;
+        if (n <= sweep_max && !getenv_old_sweep) {
+            sweep_begin(w, lo, hi);
+            return sweep_sub(sweep_sub, w, lo, hi, d, box, root);
+        }
         float tight[6];
         memcpy(tight, kEmpty, sizeof(tight));
         for (int p = lo; p < hi; p++) grow(tight, at[(size_t)p]);
