@@ -211,6 +211,13 @@ int rt_readback_rgb8(rt_context* ctx, unsigned char* rgb8, size_t n_bytes);
 /* Zero the accumulators and the sample counter. */
 int rt_reset_accum(rt_context* ctx);
 
+/* Give back the device memory the context keeps between calls for its own use: the per-path radiance buffer of the
+ * fused kernel (up to 8 GiB for a large frame at many samples per call), the wavefront pipeline's ray queues and the
+ * readback scratch.  They grow on demand and are otherwise held until rt_destroy; a long-lived context that has
+ * rendered one big frame calls this before it idles.  Scene, accumulators and sample count are untouched; the next
+ * render allocates again.  No reference counterpart (the reference frees everything at the end of main, main.cu:508-513). */
+int rt_release_scratch(rt_context* ctx);
+
 /* Use caller-owned DEVICE memory (n_floats >= rows*width*3) as the raw-sum
  * accumulator, so that the host layer can run its RCCL reduce/gather on it
  * directly.  dev_ptr == NULL returns to the internal buffer.  No reference

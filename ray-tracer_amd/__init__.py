@@ -99,7 +99,7 @@ OP_STRIDES = {OP_TRI_INTERSECT: (15, 4), OP_AABB_DIST: (12, 1), OP_SPHERE: (10, 
 TRI_FLOATS = 25
 
 RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt_render", "rt_readback", "rt_readback_rgb8",
-              "rt_reset_accum", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
+              "rt_reset_accum", "rt_release_scratch", "rt_bind_accum", "rt_set_sample_count", "rt_set_stream", "rt_resolve_device",
               "rt_trace_rays", "rt_trace_rays_noalloc", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy",
               "rt_comm_create", "rt_comm_destroy", "rt_comm_last_error", "rt_comm_size", "rt_comm_transport", "rt_comm_context",
               "rt_comm_upload_scene", "rt_comm_render", "rt_comm_reduce_sum", "rt_comm_gather_rows", "rt_comm_reset",
@@ -171,6 +171,7 @@ def core_lib() -> C.CDLL:
         L.rt_readback.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_int]
         L.rt_readback_rgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_reset_accum.argtypes = [C.c_void_p]
+        L.rt_release_scratch.argtypes = [C.c_void_p]
         L.rt_bind_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_set_sample_count.argtypes = [C.c_void_p, C.c_int64]
         L.rt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -439,6 +440,10 @@ class Renderer:
 
     def reset(self):
         self._ck(self._L.rt_reset_accum(self._h))
+
+    def release_scratch(self):
+        """Free the buffers the context keeps between calls (per-path radiance, ray queues, readback scratch)."""
+        self._ck(self._L.rt_release_scratch(self._h))
 
     def bind_accum(self, dev_ptr: int, n_floats: int):
         self._ck(self._L.rt_bind_accum(self._h, C.c_void_p(dev_ptr), n_floats))

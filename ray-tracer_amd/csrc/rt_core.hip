@@ -2154,6 +2154,22 @@ int rt_reset_accum(rt_context* c) {
     return RT_OK;
 }
 
+int rt_release_scratch(rt_context* c) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_samples) (void)hipFree(c->d_samples);
+    c->d_samples = nullptr;
+    c->samples_floats = 0;
+    if (c->d_wf) (void)hipFree(c->d_wf);
+    c->d_wf = nullptr;
+    c->wf_slots = 0;
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    return RT_OK;
+}
+
 int rt_bind_accum(rt_context* c, float* dev_ptr, size_t n_floats) {
     if (!c) return RT_ERR_INVALID;
     c->d_accum_ext = dev_ptr;

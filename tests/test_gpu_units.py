@@ -709,3 +709,33 @@ def test_sub_tree_build_is_the_same_on_any_number_of_host_threads(ob, rt, gpu, m
         got = gpu.trace_rays(rays, rt.F_BVH, want_counts=True)
         for a, b in zip(got, ref):
             assert np.array_equal(a, b), threads
+
+
+def test_release_scratch_keeps_scene_and_sums(rt, gpu, scenes):
+    """rt_release_scratch frees the buffers held between calls (per-path radiance, ray queues, readback scratch):
+    device memory comes back, the accumulated sum is still there, and the next renders -- every schedule -- allocate
+    again and give the same image."""
+    import ctypes as C
+    rt.core_lib()
+    hip = C.CDLL("libamdhip64.so.7")   # (the HIP runtime the library itself is bound to, by SONAME)
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    sc = scenes("scene_cornellbox.txt")
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=64, width=512, height=512, max_bounces=4)
+    gpu.reset(); gpu.render(p)
+    first = gpu.readback(rt.READ_AVERAGE)
+    held = free_bytes()
+    gpu.release_scratch()
+    assert free_bytes() >= held + 512 * 512 * 64 * 12                       # at least the radiance buffer came back
+    assert np.array_equal(gpu.readback(rt.READ_AVERAGE), first)             # (the readback scratch is allocated again)
+    for mode in ("megakernel", "wavefront", "lockstep", "pool"):
+        q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
+        gpu.reset(); gpu.render(q)
+        assert np.array_equal(gpu.readback(rt.READ_AVERAGE), first), mode
+        gpu.release_scratch()
