@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 
 // BIG: the scene has leaf sub-trees (rt_device.h).  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
 // (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
-template <bool STATS, bool BIG, bool EXTRA, bool COOP>
+template <bool STATS, bool BIG, bool EXTRA, bool COOP, bool TLDS = false>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
@@ -481,10 +481,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
+                trav_step_leaf<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
 #pragma unroll
                 for (int k = 1; k < RT_LEAF_STEPS; k++)
-                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG>(sc, t, stk, cn);
+                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
             }
         } else {
             if (at_inner) {
@@ -2229,6 +2229,10 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
     t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)c->sc.n_inner);
+    // a scene whose whole item stream fits (the Cornell box): the triangles too, so that a leaf step reads the LDS
+    // instead of L1 (path-parallel kernel only: its leaf step knows)
+    const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris;
+    if (with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
     t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
     t.grid = c->num_cus;
     return t;
@@ -2243,7 +2247,7 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
 }
 
 typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int, int);
-paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop) {
+paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop, bool tlds = false) {
 #define RT_V4(C) \
     rt_render_paths_kernel<false, false, false, C>, rt_render_paths_kernel<true, false, false, C>, \
     rt_render_paths_kernel<false, true, false, C>,  rt_render_paths_kernel<true, true, false, C>,  \
@@ -2251,6 +2255,12 @@ paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop) {
     rt_render_paths_kernel<false, true, true, C>,   rt_render_paths_kernel<true, true, true, C>
     static const paths_fn table[16] = {RT_V4(false), RT_V4(true)};
 #undef RT_V4
+    // the whole item stream in LDS (tiny scenes: no sub-trees there): leaf steps read the LDS
+    static const paths_fn tiny[8] = {rt_render_paths_kernel<false, false, false, false, true>, rt_render_paths_kernel<true, false, false, false, true>,
+                                     rt_render_paths_kernel<false, false, true, false, true>,  rt_render_paths_kernel<true, false, true, false, true>,
+                                     rt_render_paths_kernel<false, false, false, true, true>,  rt_render_paths_kernel<true, false, false, true, true>,
+                                     rt_render_paths_kernel<false, false, true, true, true>,   rt_render_paths_kernel<true, false, true, true, true>};
+    if (tlds && !big) return tiny[(stats ? 1 : 0) | (extra ? 2 : 0) | (coop ? 4 : 0)];
     return table[(stats ? 1 : 0) | (big ? 2 : 0) | (extra ? 4 : 0) | (coop ? 8 : 0)];
 }
 
@@ -2301,8 +2311,8 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->mega_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    for (int v = 0; v < 16; v++)
-        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0),
+    for (int v = 0; v < 32; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0, (v & 16) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     for (int v = 0; v < 8; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)pool_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
@@ -2356,7 +2366,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         S = (S + 1) / 2;
     }
     const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.n_sub > 0, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
-                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
+                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN, tc.n_cached > c->sc.n_inner);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     // the block-level ray pool (RT_F_POOL / RT_POOL=1): plain triangle scenes (no spheres, volume, ray marching, brute force)

@@ -601,11 +601,18 @@ __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* s
     visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
 }
 
-template <bool STATS, bool SUB>
-__device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn) {  // a triangle or RT_TRAV_EMPTY
+// TLDS: a scene so small that its WHOLE item stream sits in the LDS cache (n_cached = inner items + triangles).
+template <bool STATS, bool SUB, bool TLDS = false>
+__device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int n_cached = 0) {  // a triangle or RT_TRAV_EMPTY
     if (t.cur == RT_TRAV_EMPTY) {
         if (STATS) cn.leaf++;
         trav_pop(t, stk);
+        return;
+    }
+    if (TLDS) {
+        float4 q0, q1, q2, q3;
+        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);  // (the fourth piece is padding: its read is dropped)
+        visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
         return;
     }
     const float4* w = sc.items + 4 * (size_t)t.cur;

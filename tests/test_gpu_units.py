@@ -739,3 +739,23 @@ def test_release_scratch_keeps_scene_and_sums(rt, gpu, scenes):
         gpu.reset(); gpu.render(q)
         assert np.array_equal(gpu.readback(rt.READ_AVERAGE), first), mode
         gpu.release_scratch()
+
+
+def test_tiny_scene_with_its_triangles_in_lds(ob, rt, gpu, scenes, monkeypatch):
+    """A scene whose whole item stream fits the LDS cache (Cornell box) runs the path kernel's TLDS variant: leaf steps
+    read triangles from the LDS.  Same sums and counters as the oracle and as the variant that reads them from memory
+    (RT_NO_LDS_TRIS)."""
+    sc = scenes("scene_cornellbox.txt")
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=8, width=160, height=120, max_bounces=5, flags=rt.F_DEFAULT | rt.F_STATS)
+    o, ost = ob.render(sc, p, n_threads=8)
+    got = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RT_NO_LDS_TRIS", "1")
+        gpu.reset(); st = gpu.render(p)
+        img = gpu.readback()
+        assert np.array_equal(img, o), off
+        assert (st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == (ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
+        got.append((st.dev_inner_visits, st.dev_lds_inner_visits, st.dev_tri_tests))
+    assert got[0] == got[1] and got[0][0] == got[0][1] > 0      # every inner item from the LDS either way
