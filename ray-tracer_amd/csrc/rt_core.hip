@@ -490,10 +490,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (at_inner) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_inner<STATS, BIG>(sc, t, stk, cn, n_cached);
+                trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
 #pragma unroll
                 for (int k = 1; k < RT_INNER_STEPS; k++)  // (more visits before the next vote: a vote costs a tenth of a step)
-                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG>(sc, t, stk, cn, n_cached);
+                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
             }
         }
 #else

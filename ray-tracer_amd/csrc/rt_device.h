@@ -585,10 +585,10 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
 // (rt_render_paths_kernel): an iteration then executes the code of one kind only.
 __device__ __forceinline__ bool trav_at_inner(const Scene& sc, const Trav& t) { return (unsigned)t.cur < (unsigned)sc.n_inner; }
 
-template <bool STATS, bool SUB>
+template <bool STATS, bool SUB, bool ALL_CACHED = false>  // ALL_CACHED: every inner item is in the LDS (no other path compiled in)
 __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached) {  // trav_at_inner(t)
     float4 q0, q1, q2, q3;
-    if (t.cur < n_cached) {
+    if (ALL_CACHED || t.cur < n_cached) {
         if (STATS) cn.dev_cached++;
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
     } else {
