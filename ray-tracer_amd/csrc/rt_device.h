@@ -1014,7 +1014,9 @@ __device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, co
 // selection (wave_light_pdf_ordered).  Per pass over RT_LIGHT_CHUNK lights: every waiting lane marks the groups of
 // RT_LIGHT_GROUP lights whose bounds its ray can reach (all lanes at once, bounds through the scalar cache), then
 // lane after lane the wave tests the marked groups' triangles, four groups per step.
-#define RT_LIGHT_GROUP 16
+#ifndef RT_LIGHT_GROUP
+#define RT_LIGHT_GROUP 16  // (8 / 16 / 32 measured: profiles/r02_ab.txt)
+#endif
 #define RT_LIGHT_CHUNK (64 * RT_LIGHT_GROUP)
 
 // Exact sum for ONE query (wave-uniform hp, og) whatever the number of nonzero terms: pass after pass over all the
