@@ -26,7 +26,7 @@ for it in range(n_scenes):
     p.cam.aperture = float(rng.choice([0.0, 0.08])); p.cam.focus_distance = 5.0
     p.seed = int(rng.integers(0, 1 << 31)); p.sample_begin = int(rng.integers(0, 1000))
     o, ost = ob.render(sc, p, n_threads=16)
-    modes = ["megakernel"] + (["lockstep", "wavefront"] if it % 5 == 0 and not (flags & rt.F_VOLUME) else [])
+    modes = ["megakernel", "pool"] + (["lockstep", "wavefront"] if it % 5 == 0 and not (flags & rt.F_VOLUME) else [])
     for mode in modes:
         q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
         gpu.reset(); st = gpu.render(q)
