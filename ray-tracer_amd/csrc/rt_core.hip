@@ -232,6 +232,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_INNER_STEPS
 #define RT_INNER_STEPS 4  // inner-node visits per vote (a vote costs about a tenth of a visit; 1 / 2 / 3 / 4 / 6 / 8: 31.9 / 30.3 / 30.0 / 29.8 / 31.3 / 30.6 ms)
 #endif
+#ifndef RT_NT_STORE
+#define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
+                       // more bytes at the HBM: 3.18 vs 2.93 GB per frame of scene.txt; profiles/r02_ab.txt)
+#endif
 #ifndef RT_LEAF_STEPS
 #define RT_LEAF_STEPS 1   // triangle tests per vote
 #endif
@@ -388,9 +392,15 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     go = true;
                 } else {
                     float* o = samples + 3 * (size_t)path;
+#if RT_NT_STORE
+                    __builtin_nontemporal_store(e.x, o);
+                    __builtin_nontemporal_store(e.y, o + 1);
+                    __builtin_nontemporal_store(e.z, o + 2);
+#else
                     o[0] = e.x;
                     o[1] = e.y;
                     o[2] = e.z;
+#endif
                     t.cur = RT_LANE_NEW;
                 }
             }
