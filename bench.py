@@ -104,6 +104,9 @@ def parse_args():
     ap.add_argument("--bounces", type=int, default=6)
     ap.add_argument("--partition", choices=["samples", "rows"], default=None)
     ap.add_argument("--mode", choices=["wavefront", "megakernel", "lockstep", "pool"], default="megakernel")
+    ap.add_argument("--walk", choices=["shortcut", "reference"], default="shortcut",
+                    help="fused kernel: shortcut = the library's surface-area tree over the reference's leaves first, the reference's own "
+                         "tree for the rays whose result is not certified (default; same sums bit for bit); reference = RT_F_REFWALK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=None, help="use the synthetic instanced field instead of --scene")
@@ -190,6 +193,8 @@ def main():
     r.upload(scene)
     p = rt.default_params(scene.camera, spp=spp, width=W, height=H, max_bounces=args.bounces)
     p.flags |= rt.MODE_FLAGS[args.mode]
+    if args.walk == "reference":
+        p.flags |= rt.F_REFWALK
     if world > 1:
         D.partition_params(p, rank, world, args.partition, spp)
     rows = rt.band_rows_of(p)
@@ -215,6 +220,10 @@ def main():
     p_stats = rt.RenderParams.from_buffer_copy(p)
     p_stats.flags |= rt.F_STATS
     st_counts = step(p_stats)
+    # ... and one with the counters of the walk the timed steps really do (the shortcut tree, where the scene has one)
+    p_dev = rt.RenderParams.from_buffer_copy(p_stats)
+    p_dev.flags |= rt.F_SHORTCUT_STATS
+    st_dev = step(p_dev) if args.mode == "megakernel" and args.walk == "shortcut" else st_counts
     # one untimed launch with per-launch HIP events around the trace kernel (wavefront mode): its summed duration
     p_prof = rt.RenderParams.from_buffer_copy(p)
     p_prof.flags |= rt.F_PROFILE
@@ -277,13 +286,15 @@ def main():
                 "frame_kernels_ms": round(k_ms, 3)}
         # what the device requests per launch, by the level that serves it (RT_F_STATS device counters): inner items
         # from the LDS node cache, the other inner items and every triangle test from L1/L2 (HBM only on a miss)
-        lds_b = 64 * st_counts.dev_lds_inner_visits / launches
-        l2_b = (64 * (st_counts.dev_inner_visits - st_counts.dev_lds_inner_visits) + 48 * st_counts.dev_tri_tests +
-                (64 + 48 + 48) * st_counts.hits + 12 * st_counts.texel_fetches + 64 * st_counts.dev_light_tests) / launches
+        lds_b = 64 * st_dev.dev_lds_inner_visits / launches
+        l2_b = (64 * (st_dev.dev_inner_visits - st_dev.dev_lds_inner_visits) + 48 * st_dev.dev_tri_tests +
+                (64 + 48 + 48) * st_dev.hits + 12 * st_dev.texel_fetches + 64 * st_dev.dev_light_tests) / launches
         roof["device_requests"] = {
-            "inner_items_visited": int(st_counts.dev_inner_visits), "of_those_from_lds": int(st_counts.dev_lds_inner_visits),
-            "triangle_tests_run": int(st_counts.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
-            "light_tests_run": int(st_counts.dev_light_tests), "reference_walk_light_tests": int(st_counts.light_tests),
+            "walk": args.walk if args.mode == "megakernel" else "reference",
+            "inner_items_visited": int(st_dev.dev_inner_visits), "of_those_from_lds": int(st_dev.dev_lds_inner_visits),
+            "triangle_tests_run": int(st_dev.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
+            "reference_walk_inner_visits": int(st_counts.inner_visits), "shortcut_rewalks": int(st_dev.shortcut_rewalks),
+            "light_tests_run": int(st_dev.dev_light_tests), "reference_walk_light_tests": int(st_counts.light_tests),
             "lds_GBps": round(lds_b / launch_s / 1e9, 1), "lds_peak_GBps": 150000.0,
             "l2_GBps": round(l2_b / launch_s / 1e9, 1), "l2_peak_GBps": 34500.0}
         roof["algorithmic_bytes_per_launch"] = int(dom_bytes / launches)
@@ -354,7 +365,7 @@ def main():
             "data": "bundled scene geometry/textures, synthetic camera batch" if args.synth_instances == 0 else "synthetic",
             "config": {"workload": workload, "preset": args.config, "width": W, "height": H, "spp_per_gpu": spp,
                        "spp_total": spp * world if args.partition == "samples" else spp, "max_bounces": args.bounces,
-                       "partition": "none" if world == 1 else args.partition, "ranks_seen_by_rccl": world, "mode": args.mode,
+                       "partition": "none" if world == 1 else args.partition, "ranks_seen_by_rccl": world, "mode": args.mode, "walk": args.walk if args.mode == "megakernel" else "reference",
                        "wavefront_iterations": int(st_counts.iterations),
                        "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
                        "spp_per_sec_1080p": round(total_paths / step_s / (1920 * 1080), 2)},

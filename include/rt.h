@@ -131,6 +131,15 @@ enum {
                                    bundled scenes, bit-identical sums); plain triangle scenes only -- with RT_F_SPHERES
                                    and spheres, RT_F_VOLUME, RT_F_RAYMARCH or without RT_F_BVH the ordinary fused
                                    kernel runs.  Also switched on by the environment variable RT_POOL=1. */
+    RT_F_REFWALK = 1 << 14,     /* every closest-hit search walks the reference's own tree.  Without it the fused
+                                   path-parallel kernel searches a surface-area tree of the library's own over the
+                                   reference's leaves first (the SHORTCUT TREE, rt_device.h) and keeps the result only
+                                   where a per-ray certificate shows that the reference's walk returns the same
+                                   triangle; other rays walk the reference's tree after all.  Same sums bit for bit,
+                                   fewer node visits.  Implied by RT_F_STATS (whose counters describe the reference's
+                                   walk), RT_F_VOLUME, RT_F_RAYMARCH, brute force and the other schedules. */
+    RT_F_SHORTCUT_STATS = 1 << 15, /* with RT_F_STATS: keep the shortcut tree; the dev_* counters and shortcut_rewalks then
+                                   say what that walk does, inner_visits / leaf_visits / tri_tests are not the reference's */
     RT_F_PROFILE = 1 << 10,     /* HIP-event timing of every launch of the dominant kernel (rt_render_stats.trace_ms) */
     RT_F_DEFAULT = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | RT_F_BVH
 };
@@ -173,6 +182,7 @@ typedef struct rt_render_stats {
     uint64_t dev_lds_inner_visits; /* of those, served by the LDS node cache instead of L2 / HBM */
     uint64_t dev_tri_tests;        /* triangle tests really run, 48 B each */
     uint64_t dev_light_tests;      /* light-triangle pdf tests really run (after the culling of light groups), 64 B each */
+    uint64_t shortcut_rewalks;     /* searches whose shortcut-tree result was not certified and that walked the reference's tree again */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };
@@ -306,6 +316,10 @@ typedef struct rt_layout_info {
     int32_t depth;       /* of the whole structure = traversal stack entries */
     float box_pad;       /* padding of every box the library adds */
     float cull_far;      /* padded boxes cull only for rays starting within this of the origin */
+    int32_t n_short;     /* shortcut-tree nodes among the inner items (0: none built) */
+    int32_t short_root;  /* item index of the shortcut tree's root, -1 without one */
+    int32_t short_base;  /* first item of the window the shortcut walk caches in LDS */
+    int32_t short_depth; /* traversal stack entries of the shortcut walk */
 } rt_layout_info;
 int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
 int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places);

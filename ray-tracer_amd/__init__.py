@@ -70,7 +70,7 @@ class RenderStats(C.Structure):
                 ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64),
                 ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32),
                 ("dev_inner_visits", C.c_uint64), ("dev_lds_inner_visits", C.c_uint64), ("dev_tri_tests", C.c_uint64),
-                ("dev_light_tests", C.c_uint64)]
+                ("dev_light_tests", C.c_uint64), ("shortcut_rewalks", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,6 +85,8 @@ F_PROFILE = 1 << 10
 F_WAVEFRONT = 1 << 11
 F_LOCKSTEP = 1 << 12
 F_POOL = 1 << 13
+F_REFWALK = 1 << 14
+F_SHORTCUT_STATS = 1 << 15
 # the three schedules of the same arithmetic (bit-identical results)
 MODE_FLAGS = {"megakernel": F_MEGAKERNEL, "lockstep": F_MEGAKERNEL | F_LOCKSTEP, "wavefront": F_WAVEFRONT,
               "pool": F_MEGAKERNEL | F_POOL}
@@ -363,7 +365,8 @@ def band_rows_of(params: RenderParams) -> int:
 
 class LayoutInfo(C.Structure):  # rt_layout_info, include/rt.h
     _fields_ = [("n_inner", C.c_int32), ("n_sub", C.c_int32), ("n_tris", C.c_int32), ("root_entry", C.c_int32),
-                ("depth", C.c_int32), ("box_pad", C.c_float), ("cull_far", C.c_float)]
+                ("depth", C.c_int32), ("box_pad", C.c_float), ("cull_far", C.c_float), ("n_short", C.c_int32),
+                ("short_root", C.c_int32), ("short_base", C.c_int32), ("short_depth", C.c_int32)]
 
 
 def device_layout(scene: "Scene"):

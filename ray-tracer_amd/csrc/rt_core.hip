@@ -227,6 +227,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_SUB_GAIN 1.0f        // ... by this factor at least,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
+#define RT_REF_FRONT 512         // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
+#define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
+#define RT_SHORT_SWEEP_MAX 2048  // shortcut tree: full surface-area sweep up to this many leaves per node, 32 bins above
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
 #ifndef RT_INNER_STEPS
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 
 // BIG: the scene has leaf sub-trees (rt_device.h).  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
 // (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
-template <bool STATS, bool BIG, bool EXTRA, bool COOP, bool TLDS = false>
+// FAST: closest-hit searches go down the shortcut tree first (rt_device.h; the scene has one, no STATS of the reference's walk).
+template <bool STATS, bool BIG, bool EXTRA, bool COOP, bool TLDS = false, bool FAST = false>
 __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                                                                               unsigned int n_paths, int n_mats_lds) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
+    const int cache_base = FAST ? sc.short_base : 0;  // the LDS holds items [cache_base, cache_base + n_cached)
+    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[4 * (size_t)cache_base + i];
     int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     // the material table behind the stacks (n_mats_lds = 0: too many materials, they stay in device memory)
     const int mats_lds = n_mats_lds > 0 ? (int)(RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16) : -1;
@@ -297,6 +302,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     t.sp = 0;
     t.hitTri = -1;
     t.minD2 = 1e12f;
+    t.rival = -1.0f;
+    t.bestLeaf = -1;
+    t.slack = 0.0f;
 
     for (;;) {
         const unsigned long long mNeed = __ballot((unsigned)(t.cur + 2) < 2u);  // RT_TRAV_DONE or RT_LANE_NEW
@@ -306,6 +314,13 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
             if ((unsigned)(t.cur + 2) < 2u) RT_PROF_LANE(cn, 4);
+            if (FAST && t.cur == RT_TRAV_DONE && !short_certified(sc, t)) {
+                // the shortcut walk's result does not prove what the reference's walk returns: this lane walks the
+                // reference's tree now (main.cu:221-283) and comes back to a later vertex pass
+                if (STATS) cn.rewalks++;
+                trav_begin(sc, t, t.o(), t.d);
+                t.rival = -1.0f;
+            }
             bool go = false;        // this lane holds a ray whose traversal starts in this pass
             PathState ray;
             f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
@@ -464,6 +479,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (go) {  // main.cu:221-236
                 if (STATS) cn.rays++;
                 trav_begin(sc, t, ro, t.d, marching ? len2(marchVel) : 1e12f);
+                if (FAST) short_begin(sc, t);
                 if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
             }
             RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
@@ -491,19 +507,19 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_leaf<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
+                trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
 #pragma unroll
                 for (int k = 1; k < RT_LEAF_STEPS; k++)
-                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
+                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
             }
         } else {
             if (at_inner) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
-                trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
+                trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
                 for (int k = 1; k < RT_INNER_STEPS; k++)  // (more visits before the next vote: a vote costs a tenth of a step)
-                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached);
+                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
             }
         }
 #else
@@ -518,9 +534,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
     if (STATS) {
-        uint32_t v[12] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights};
+        uint32_t v[13] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights,
+                          cn.rewalks};
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < 13; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
@@ -1101,9 +1118,10 @@ struct rt_context {
     // scene (device)
     bool has_scene = false;
     Scene sc{};
-    void* d_items = nullptr; void* d_cold = nullptr; void* d_place = nullptr;
+    void* d_items = nullptr; void* d_cold = nullptr; void* d_place = nullptr; void* d_refboxes = nullptr;
     void* d_mats = nullptr; void* d_lights = nullptr; void* d_spheres = nullptr; void* d_tex = nullptr;
     int bvh_depth = 0;
+    int short_depth = 0;  // stack entries of the shortcut walk (0: no shortcut tree)
 
     // accumulators
     float* d_accum_own = nullptr;
@@ -1146,7 +1164,7 @@ int set_err(rt_context* c, int code, const std::string& msg) {
     } while (0)
 
 void free_scene(rt_context* c) {
-    void** ptrs[] = {&c->d_items, &c->d_place, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
+    void** ptrs[] = {&c->d_items, &c->d_place, &c->d_refboxes, &c->d_cold, &c->d_mats, &c->d_lights, &c->d_spheres, &c->d_tex};
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -1355,7 +1373,9 @@ struct HostLayout {
     RawFloats items, cold;
     std::vector<float> mats, lights, spheres;
     std::vector<int> place;  // reference triangle id -> place in the item stream
+    std::vector<float> ref_boxes;  // the reference's node boxes as uploaded, 8 floats per node (the shortcut tree's certificate reads the leaf's)
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
+    int n_short = 0, short_root = RT_TRAV_DONE, short_base = 0, short_depth = 0;  // shortcut tree (rt_device.h): nodes, root item, first item of its LDS window, stack entries
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
 };
@@ -1423,6 +1443,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
     std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
     std::vector<int> leaf_end((size_t)std::max(ntri, 1), 0), sub_root((size_t)std::max(nn, 1), -1);
+    std::vector<int> leaf_node((size_t)std::max(ntri, 1), 0);  // place -> the reference leaf (node index) that holds it
     std::vector<unsigned char> tflags((size_t)std::max(ntri, 1), 0);
     std::vector<char> covered((size_t)std::max(ntri, 1), 0);
     for (int i = 0; i < ntri; i++) at[(size_t)i] = i;
@@ -1501,6 +1522,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         std::vector<float> suffix;
         std::vector<std::pair<int, int>> roots;  // (leaf node, root in subs)
         int deepest = 0;
+        int leaf_deepest = 0, max_below_leaf = 0;  // deepest level of the sub-tree being built; most levels any sub-tree adds below its leaf
     };
     // The sweep builder below a node of at most sweep_max triangles.  Its triangles are sorted ONCE per axis (by centroid,
     // ties by triangle id: as one 64-bit key, the float's bits made monotonic, -0 folded into +0); a split keeps the
@@ -1518,6 +1540,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         memcpy(box, tight, sizeof(tight));
         for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
         w.deepest = std::max(w.deepest, d);
+        w.leaf_deepest = std::max(w.leaf_deepest, d);
         int mid = -1;
         const float pa = half_area(tight);
         if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
@@ -1633,6 +1656,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         memcpy(box, tight, sizeof(tight));
         for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }  // a sub-tree box must never make the ray miss a triangle it hits
         w.deepest = std::max(w.deepest, d);
+        w.leaf_deepest = std::max(w.leaf_deepest, d);
         int mid = -1;
         const float pa = half_area(tight);
         if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
@@ -1733,6 +1757,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             covered[(size_t)first + k] = 1;
             tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
             leaf_end[(size_t)first + k] = first + cnt;
+            leaf_node[(size_t)first + k] = i;
         }
         // (the traversal stack must have room below this leaf)
         if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
@@ -1748,10 +1773,12 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 const int i = candidates[ci];
                 const int first = s->nodes[i].tri_offs / RT_TRI_FLOATS, cnt = s->nodes[i].tri_len / RT_TRI_FLOATS;
                 float box[6];
+                w.leaf_deepest = depth[i];
                 const int root = build_sub(build_sub, w, first, first + cnt, depth[i], box, true);
                 if (root >= 0) {
                     w.subs[(size_t)root].cnt = cnt;
                     w.roots.push_back({i, root});
+                    w.max_below_leaf = std::max(w.max_below_leaf, w.leaf_deepest - depth[i]);
                 }
             }
         };
@@ -1796,17 +1823,218 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         }
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
-    n_inner = n_top + n_sub;
+    // ---- SHORTCUT TREE (rt_device.h): a surface-area tree of this library's own over the reference's non-empty LEAVES
+    //      (each with whatever hangs below it: its triangles or its sub-tree), padded boxes, walked with the sub-trees'
+    //      slack rule.  It finds the closest hit in fewer visits than the reference's mean-split tree; a per-ray
+    //      certificate (exact box test of the hit's reference leaf against the runner-up from another leaf) says whether
+    //      the reference's own walk must return the same triangle, and the ray walks the reference's tree if not.
+    //      Needs the reference's boxes to be nested (child inside parent), as its builder makes them.
+    struct ShortPrim { float b[6]; float c[3]; float cost; int node; };
+    struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(reference leaf node)
+    std::vector<ShortNode> shorts;
+    int short_root = -1, short_levels = 0, below_leaf = 0;
+    for (int wi = 0; wi < n_workers; wi++) below_leaf = std::max(below_leaf, work[(size_t)wi].max_below_leaf);
+    {
+        bool want = nn > 1 && ntri >= sub_min_tris && !getenv("RT_NO_SHORTCUT");
+        for (int i = 0; i < nn && want; i++) {
+            const rt_bvh_node& n = s->nodes[i];
+            if (n.child_a == -1) continue;
+            for (int ch : {n.child_a, n.child_b})
+                for (int k = 0; k < 3; k++)
+                    if (!(s->nodes[ch].bbox_min[k] >= n.bbox_min[k] && s->nodes[ch].bbox_max[k] <= n.bbox_max[k])) want = false;
+        }
+        std::vector<ShortPrim> prims;
+        if (want) {
+            for (int i = 0; i < nn; i++) {
+                const rt_bvh_node& n = s->nodes[i];
+                if (n.child_a != -1 || n.tri_len == 0) continue;
+                const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+                ShortPrim p;
+                memcpy(p.b, kEmpty, sizeof(p.b));
+                for (int k = 0; k < cnt; k++) grow(p.b, at[(size_t)first + k]);
+                for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.b[k] + p.b[3 + k]);
+                p.cost = 1.0f + (float)std::min(cnt, 4);  // steps a ray spends below the leaf's box, roughly
+                p.node = i;
+                prims.push_back(p);
+            }
+        }
+        const int np = (int)prims.size();
+        int lg = 0;
+        while ((1 << lg) < np) lg++;
+        // levels the shortcut tree may have: the stack holds RT_SHORT_STACK_MAX entries and the sub-trees need below_leaf of them
+        const int levels_max = std::min(RT_SHORT_STACK_MAX - below_leaf, lg + 8);
+        if (np >= 2 && lg <= levels_max) {
+            shorts.resize((size_t)np - 1);  // the node that splits [lo, hi) at mid is shorts[mid - 1]: no two nodes share a split point
+            std::vector<int> ids((size_t)np);
+            for (int k = 0; k < np; k++) ids[(size_t)k] = k;
+            std::atomic<int> deepest_short{0};
+            auto union_box = [&](int lo, int hi, float* box) {
+                memcpy(box, kEmpty, 6 * sizeof(float));
+                for (int p = lo; p < hi; p++) {
+                    const float* b = prims[(size_t)ids[(size_t)p]].b;
+                    for (int c = 0; c < 3; c++) { box[c] = std::min(box[c], b[c]); box[3 + c] = std::max(box[3 + c], b[3 + c]); }
+                }
+            };
+            // returns the entry of the node over ids[lo, hi) standing at level d (root: 0) and its padded box
+            auto build_short = [&](auto&& self, int lo, int hi, int d, float* box) -> int {
+                const int n = hi - lo;
+                union_box(lo, hi, box);
+                for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
+                int seen = deepest_short.load();
+                while (seen < d && !deepest_short.compare_exchange_weak(seen, d)) {}
+                if (n == 1) return ~prims[(size_t)ids[(size_t)lo]].node;
+                // a side may keep at most 2^(levels_max - d - 1) leaves: what is left of the levels can still hold them
+                const int room = levels_max - d - 1;
+                const int side_max = room >= 30 ? n : std::min(n, 1 << room);
+                const int k_lo = std::max(1, n - side_max), k_hi = std::min(n - 1, side_max);  // left = the first k, k in [k_lo, k_hi]
+                int best_axis = -1, best_k = -1;
+                float best = 3e38f;
+                std::vector<float> suffix;
+                auto by_axis = [&](int axis) {
+                    std::sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) {
+                        const float ca = prims[(size_t)a].c[axis], cb = prims[(size_t)b].c[axis];
+                        return ca < cb || (ca == cb && prims[(size_t)a].node < prims[(size_t)b].node);
+                    });
+                };
+                if (n <= RT_SHORT_SWEEP_MAX) {
+                    suffix.resize(2 * ((size_t)n + 1));
+                    for (int axis = 0; axis < 3; axis++) {
+                        by_axis(axis);
+                        float bx[6], w = 0.f;
+                        memcpy(bx, kEmpty, sizeof(bx));
+                        for (int k = n - 1; k >= 1; k--) {
+                            const ShortPrim& p = prims[(size_t)ids[(size_t)(lo + k)]];
+                            for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], p.b[c]); bx[3 + c] = std::max(bx[3 + c], p.b[3 + c]); }
+                            w += p.cost;
+                            suffix[2 * (size_t)k] = half_area(bx);
+                            suffix[2 * (size_t)k + 1] = w;
+                        }
+                        memcpy(bx, kEmpty, sizeof(bx));
+                        w = 0.f;
+                        for (int k = 1; k < n; k++) {
+                            const ShortPrim& p = prims[(size_t)ids[(size_t)(lo + k - 1)]];
+                            for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], p.b[c]); bx[3 + c] = std::max(bx[3 + c], p.b[3 + c]); }
+                            w += p.cost;
+                            if (k < k_lo || k > k_hi) continue;
+                            const float cst = half_area(bx) * w + suffix[2 * (size_t)k] * suffix[2 * (size_t)k + 1];
+                            if (cst < best) { best = cst; best_axis = axis; best_k = k; }
+                        }
+                    }
+                    if (best_axis >= 0 && best_axis != 2) by_axis(best_axis);
+                } else {  // 32 bins of the centroid range per axis; the leaves are then partitioned, not sorted
+                    const int NB = 32;
+                    float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
+                    for (int p = lo; p < hi; p++)
+                        for (int k = 0; k < 3; k++) {
+                            const float cc = prims[(size_t)ids[(size_t)p]].c[k];
+                            cmn[k] = std::min(cmn[k], cc);
+                            cmx[k] = std::max(cmx[k], cc);
+                        }
+                    int best_bin = -1;
+                    auto bin_of = [&](const ShortPrim& p, int axis) {
+                        const float wdt = cmx[axis] - cmn[axis];
+                        const int b = (int)((p.c[axis] - cmn[axis]) / wdt * (float)NB);
+                        return std::min(NB - 1, std::max(0, b));
+                    };
+                    for (int axis = 0; axis < 3; axis++) {
+                        if (!(cmx[axis] > cmn[axis])) continue;
+                        float bb[NB][6], bw[NB];
+                        int bn[NB];
+                        for (int b = 0; b < NB; b++) { memcpy(bb[b], kEmpty, sizeof(bb[b])); bw[b] = 0.f; bn[b] = 0; }
+                        for (int p = lo; p < hi; p++) {
+                            const ShortPrim& pr = prims[(size_t)ids[(size_t)p]];
+                            const int b = bin_of(pr, axis);
+                            for (int c = 0; c < 3; c++) { bb[b][c] = std::min(bb[b][c], pr.b[c]); bb[b][3 + c] = std::max(bb[b][3 + c], pr.b[3 + c]); }
+                            bw[b] += pr.cost;
+                            bn[b]++;
+                        }
+                        float ra[NB], rw[NB], bx[6], w = 0.f;
+                        memcpy(bx, kEmpty, sizeof(bx));
+                        for (int b = NB - 1; b >= 1; b--) {
+                            for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], bb[b][c]); bx[3 + c] = std::max(bx[3 + c], bb[b][3 + c]); }
+                            w += bw[b];
+                            ra[b] = bn[b] || w > 0.f ? half_area(bx) : 0.f;
+                            rw[b] = w;
+                        }
+                        memcpy(bx, kEmpty, sizeof(bx));
+                        w = 0.f;
+                        int k = 0;
+                        for (int b = 1; b < NB; b++) {  // left = bins [0, b)
+                            for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], bb[b - 1][c]); bx[3 + c] = std::max(bx[3 + c], bb[b - 1][3 + c]); }
+                            w += bw[b - 1];
+                            k += bn[b - 1];
+                            if (k < k_lo || k > k_hi) continue;
+                            const float cst = half_area(bx) * w + ra[b] * rw[b];
+                            if (cst < best) { best = cst; best_axis = axis; best_k = k; best_bin = b; }
+                        }
+                    }
+                    if (best_axis >= 0) {
+                        const int axis = best_axis, bsplit = best_bin;
+                        std::stable_partition(ids.begin() + lo, ids.begin() + hi, [&](int a) { return bin_of(prims[(size_t)a], axis) < bsplit; });
+                    }
+                }
+                if (best_axis < 0) {  // no admissible surface-area split (or every centroid in one place): halves along the widest axis
+                    float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
+                    for (int p = lo; p < hi; p++)
+                        for (int k = 0; k < 3; k++) {
+                            const float cc = prims[(size_t)ids[(size_t)p]].c[k];
+                            cmn[k] = std::min(cmn[k], cc);
+                            cmx[k] = std::max(cmx[k], cc);
+                        }
+                    int axis = 0;
+                    for (int k = 1; k < 3; k++)
+                        if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+                    by_axis(axis);
+                    best_k = n / 2;
+                }
+                const int mid = lo + best_k;
+                float ba[6], bb2[6];
+                int ea, eb;
+                if (n >= (1 << 14) && d < 4) {  // the big halves on two host threads (disjoint ranges of ids and of shorts)
+                    int ea_t = 0;
+                    std::thread th([&] { ea_t = self(self, lo, mid, d + 1, ba); });
+                    eb = self(self, mid, hi, d + 1, bb2);
+                    th.join();
+                    ea = ea_t;
+                } else {
+                    ea = self(self, lo, mid, d + 1, ba);
+                    eb = self(self, mid, hi, d + 1, bb2);
+                }
+                ShortNode& nd = shorts[(size_t)mid - 1];
+                memcpy(nd.box[0], ba, sizeof(ba));
+                memcpy(nd.box[1], bb2, sizeof(bb2));
+                nd.e[0] = ea;
+                nd.e[1] = eb;
+                return mid - 1;
+            };
+            float root_box[6];
+            short_root = build_short(build_short, 0, np, 0, root_box);
+            short_levels = deepest_short.load();
+        }
+    }
+    const int n_short = (int)shorts.size();
+    timer.stage("shortcut tree");
+    n_inner = n_top + n_sub + n_short;
     // Item index of every inner node, the reference's and the sub-trees' alike.  The RT_ITEM_FRONT nodes with the biggest
     // boxes come first, biggest first (ties: the reference's nodes in their order, then the sub-tree nodes in theirs): a
     // random ray meets a box in proportion to its area, and the LDS node cache of the kernels holds the items from the
     // front.  Behind them the reference's BFS order and the sub-trees' depth-first order stay as they are, which keeps
     // neighbours in the tree close in memory.  "Node q" below: q < nn is the reference's node q, q >= nn sub-tree node q - nn.
-    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0);
+    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0), short_index((size_t)std::max(n_short, 1), 0);
+    int short_base = 0;
     {
         struct Key { float area; int kind, id; };
         auto bigger = [](const Key& a, const Key& b) { return a.area != b.area ? a.area > b.area : (a.kind != b.kind ? a.kind < b.kind : a.id < b.id); };
-        const size_t nq = (size_t)nn + (size_t)n_sub;
+        // "node q": q < nn the reference's node q, then the sub-tree nodes, then the shortcut nodes
+        const size_t nq = (size_t)nn + (size_t)n_sub + (size_t)n_short;
+        auto union_area = [&](const float* A, const float* B) {
+            float u[6];
+            for (int c = 0; c < 3; c++) {
+                u[c] = std::min(A[c], B[c]);
+                u[3 + c] = std::max(A[3 + c], B[3 + c]);
+            }
+            return half_area(u);
+        };
         auto key_of = [&](size_t q, Key& k) -> bool {  // false: a leaf of the reference's tree (no item of its own)
             if (q < (size_t)nn) {
                 const rt_bvh_node& nd = s->nodes[q];
@@ -1815,43 +2043,61 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 k = {q == 0 ? 3e38f : half_area(b), 0, (int)q};  // (the root first, whatever its box)
                 return true;
             }
-            const SubNode& nd = subs[q - (size_t)nn];
-            float u[6];
-            for (int c = 0; c < 3; c++) {
-                u[c] = std::min(nd.box[0][c], nd.box[1][c]);
-                u[3 + c] = std::max(nd.box[0][3 + c], nd.box[1][3 + c]);
+            if (q < (size_t)nn + (size_t)n_sub) {
+                const SubNode& nd = subs[q - (size_t)nn];
+                k = {union_area(nd.box[0], nd.box[1]), 1, (int)(q - (size_t)nn)};
+                return true;
             }
-            k = {half_area(u), 1, (int)(q - (size_t)nn)};
+            const int j = (int)(q - (size_t)nn - (size_t)n_sub);
+            const ShortNode& nd = shorts[(size_t)j];
+            k = {j == short_root ? 3e38f : union_area(nd.box[0], nd.box[1]), 2, j};
             return true;
         };
         const size_t front = getenv("RT_ITEMS_BFS") ? 0 : std::min<size_t>(RT_ITEM_FRONT, (size_t)n_inner);  // (RT_ITEMS_BFS: experiments only)
-        // every range keeps its own `front` biggest; the biggest of those are the biggest of all (the order is total)
-        std::vector<std::vector<Key>> top((size_t)n_workers_max);
-        if (front)
-            par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
-                std::vector<Key>& v = top[(size_t)wi];
-                Key k;
-                for (size_t q = lo; q < hi; q++) {
-                    if (!key_of(q, k)) continue;
-                    v.push_back(k);
-                    if (v.size() >= 4 * front) {
-                        std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)front, v.end(), bigger);
-                        v.resize(front);
+        // the `count` biggest nodes of the kinds in `kinds` (bit per kind), biggest first: every range keeps its own
+        // `count` biggest; the biggest of those are the biggest of all (the order is total)
+        auto select = [&](int kinds, size_t count) {
+            std::vector<std::vector<Key>> top((size_t)n_workers_max);
+            if (count)
+                par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
+                    std::vector<Key>& v = top[(size_t)wi];
+                    Key k;
+                    for (size_t q = lo; q < hi; q++) {
+                        if (!key_of(q, k) || !((kinds >> k.kind) & 1)) continue;
+                        v.push_back(k);
+                        if (v.size() >= 4 * count) {
+                            std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)count, v.end(), bigger);
+                            v.resize(count);
+                        }
                     }
-                }
-            });
+                });
+            std::vector<Key> big;
+            for (auto& v : top) big.insert(big.end(), v.begin(), v.end());
+            if (big.size() > count) {
+                std::nth_element(big.begin(), big.begin() + (std::ptrdiff_t)count, big.end(), bigger);
+                big.resize(count);
+            }
+            std::sort(big.begin(), big.end(), bigger);
+            return big;
+        };
+        // Without a shortcut tree: reference and sub-tree nodes in ONE order by area (what the reference's walk meets most).
+        // With one the kernels cache one of two windows of the item stream: the reference's walk items [0, n_cached) --
+        // RT_REF_FRONT of its own biggest nodes, then the window below --, the shortcut walk items [short_base, short_base +
+        // n_cached): the biggest shortcut and sub-tree nodes, which is all it visits.
         std::vector<Key> big;
-        for (auto& v : top) big.insert(big.end(), v.begin(), v.end());
-        if (big.size() > front) {
-            std::nth_element(big.begin(), big.begin() + (std::ptrdiff_t)front, big.end(), bigger);
-            big.resize(front);
+        if (n_short > 0 && front) {
+            big = select(1, std::min<size_t>(RT_REF_FRONT, (size_t)n_top));
+            short_base = (int)big.size();
+            const std::vector<Key> rest = select(2 | 4, front);
+            big.insert(big.end(), rest.begin(), rest.end());
+        } else {
+            big = select(1 | 2 | 4, front);
         }
-        std::sort(big.begin(), big.end(), bigger);
         std::vector<char> taken(std::max<size_t>(nq, 1), 0);
         for (size_t k = 0; k < big.size(); k++) {
             const Key& b = big[k];
-            taken[b.kind == 0 ? (size_t)b.id : (size_t)nn + (size_t)b.id] = 1;
-            (b.kind == 0 ? inner_index[(size_t)b.id] : sub_index[(size_t)b.id]) = (int)k;
+            taken[b.kind == 0 ? (size_t)b.id : (b.kind == 1 ? (size_t)nn + (size_t)b.id : (size_t)nn + (size_t)n_sub + (size_t)b.id)] = 1;
+            (b.kind == 0 ? inner_index[(size_t)b.id] : (b.kind == 1 ? sub_index[(size_t)b.id] : short_index[(size_t)b.id])) = (int)k;
         }
         // the others: front + their rank among the nodes not taken (count per range, prefix, assign)
         std::vector<size_t> cnt((size_t)n_workers_max + 1, 0);
@@ -1868,13 +2114,16 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 if (taken[q]) continue;
                 if (q < (size_t)nn) {
                     if (s->nodes[q].child_a != -1) inner_index[q] = (int)k++;
-                } else {
+                } else if (q < (size_t)nn + (size_t)n_sub) {
                     sub_index[q - (size_t)nn] = (int)k++;
+                } else {
+                    short_index[q - (size_t)nn - (size_t)n_sub] = (int)k++;
                 }
             }
         });
     }
     if ((long long)n_inner + ntri > 0x7fffffffLL / 4) return fail(RT_ERR_LIMIT, "scene too large for 32-bit item indices");
+
     auto entry_of = [&](int node) -> int {
         const rt_bvh_node& n = s->nodes[node];
         if (n.child_a != -1) return inner_index[node];
@@ -1902,7 +2151,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
             h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
             h[9] = i2f((int)tflags[p]); h[10] = i2f(leaf_end[p]); h[11] = i2f(tri);
-            h[12] = h[13] = h[14] = h[15] = 0.f;
+            h[12] = i2f(leaf_node[p]);
+            h[13] = h[14] = h[15] = 0.f;
             const float* u = tris + p * RT_TRI_FLOATS;                    // cold data stays in the reference's order
             float* cd = &cold[p * 16];
             for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
@@ -1938,6 +2188,25 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             w[15] = i2f(1);
         }
     });
+    par_ranges((size_t)n_short, [&](int, size_t lo, size_t hi) {  // shortcut nodes: sub-tree nodes that stand for no leaf of their own
+        for (size_t j = lo; j < hi; j++) {
+            const ShortNode& nd = shorts[j];
+            float* w = &items[(size_t)short_index[j] * 16];
+            const float *A = nd.box[0], *B = nd.box[1];
+            w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
+            w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
+            w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
+            for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : entry_of(~nd.e[k]));
+            w[14] = i2f(0);
+            w[15] = i2f(2);
+        }
+    });
+    L.ref_boxes.assign((size_t)std::max(nn, 1) * 8, 0.f);
+    for (int i = 0; i < nn; i++)
+        for (int k = 0; k < 3; k++) {
+            L.ref_boxes[(size_t)i * 8 + k] = s->nodes[i].bbox_min[k];
+            L.ref_boxes[(size_t)i * 8 + 4 + k] = s->nodes[i].bbox_max[k];
+        }
 
     timer.stage("item stream, cold data");
     // ---- materials: decoded colour (Vec3::fromColorInt, vec3.h:118-123)
@@ -2056,6 +2325,10 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.n_sub = n_sub;
     L.n_tris = ntri;
     L.depth = deepest;
+    L.n_short = n_short;
+    L.short_root = short_root >= 0 ? short_index[(size_t)short_root] : RT_TRAV_DONE;
+    L.short_base = short_base;
+    L.short_depth = n_short > 0 ? short_levels + below_leaf : 0;
     L.light_box_off = light_box_off;
     L.light_place_off = light_place_off;
     L.scene_scale = scene_scale;
@@ -2076,6 +2349,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     const int nn = s->n_nodes;
     free_scene(c);
     if ((rc = upload_buf(c, &c->d_place, L.place.data(), L.place.size() * 4)) != RT_OK) return rc;
+    if ((rc = upload_buf(c, &c->d_refboxes, L.ref_boxes.data(), L.ref_boxes.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_items, L.items.data(), L.items.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_cold, L.cold.data(), L.cold.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_mats, L.mats.data(), L.mats.size() * 4)) != RT_OK) return rc;
@@ -2086,6 +2360,9 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
     sc.tri_place = (const int*)c->d_place;
+    sc.ref_boxes = (const float4*)c->d_refboxes;
+    sc.short_root = L.short_root;
+    sc.short_base = L.short_base;
     sc.n_inner = L.n_inner;
     sc.n_sub = L.n_sub;
     sc.cull_far = RT_CULL_FAR * L.scene_scale;
@@ -2109,6 +2386,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     }
     timer.stage("device allocations, copies");
     c->bvh_depth = L.depth;
+    c->short_depth = L.short_depth;
     c->has_scene = true;
     return RT_OK;
 }
@@ -2145,6 +2423,10 @@ int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items,
         info->depth = h->L.depth;
         info->box_pad = h->L.box_pad;
         info->cull_far = RT_CULL_FAR * h->L.scene_scale;
+        info->n_short = h->L.n_short;
+        info->short_root = h->L.short_root;
+        info->short_base = h->L.short_base;
+        info->short_depth = h->L.short_depth;
     }
     if (items) *items = h->L.items.data();
     if (places) *places = h->L.place.data();
@@ -2230,19 +2512,20 @@ struct TraceCfg {
 };
 
 #define RT_LDS_MATS_MAX 128  // material tables up to this size go to LDS in the path kernel (48 B each)
-TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = false) {
+TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = false, bool fast = false) {
     TraceCfg t;
-    t.stack_entries = std::max(c->bvh_depth, 1);
+    // (shortcut walk: a search that is not certified walks the reference's tree with the same stack)
+    t.stack_entries = std::max(fast ? std::max(c->bvh_depth, c->short_depth) : c->bvh_depth, 1);
     t.n_mats_lds = (with_mats && c->sc.n_mats <= RT_LDS_MATS_MAX && !getenv("RT_NO_LDS_MATS")) ? c->sc.n_mats : 0;
     const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48;
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
-    t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)c->sc.n_inner);
+    t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)(c->sc.n_inner - (fast ? c->sc.short_base : 0)));
     // a scene whose whole item stream fits (the Cornell box): the triangles too, so that a leaf step reads the LDS
     // instead of L1 (path-parallel kernel only: its leaf step knows)
     const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris;
-    if (with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
+    if (with_mats && !fast && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
     t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
     t.grid = c->num_cus;
     return t;
@@ -2257,7 +2540,11 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
 }
 
 typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int, int);
-paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop, bool tlds = false) {
+paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop, bool tlds = false, bool fast = false) {
+    // the shortcut walk: plain triangle scenes with sub-tree style nodes (its own), no extras
+    static const paths_fn shortcut[4] = {rt_render_paths_kernel<false, true, false, false, false, true>, rt_render_paths_kernel<true, true, false, false, false, true>,
+                                         rt_render_paths_kernel<false, true, false, true, false, true>,  rt_render_paths_kernel<true, true, false, true, false, true>};
+    if (fast) return shortcut[(stats ? 1 : 0) | (coop ? 2 : 0)];
 #define RT_V4(C) \
     rt_render_paths_kernel<false, false, false, C>, rt_render_paths_kernel<true, false, false, C>, \
     rt_render_paths_kernel<false, true, false, C>,  rt_render_paths_kernel<true, true, false, C>,  \
@@ -2324,6 +2611,9 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     for (int v = 0; v < 32; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0, (v & 16) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    for (int v = 0; v < 4; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, true, false, (v & 2) != 0, false, true),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     for (int v = 0; v < 8; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)pool_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -2353,7 +2643,14 @@ int render_lockstep(rt_context* c, const Params& P, float* accum, bool want_stat
 // Path-parallel fused kernel: the call's samples in chunks of S; per chunk one persistent launch that
 // writes one radiance per path, and one pass that adds them to the accumulator in sample order.
 int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, bool profile, rt_render_stats* out) {
-    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true);
+    // the block-level ray pool (RT_F_POOL / RT_POOL=1): plain triangle scenes (no spheres, volume, ray marching, brute force)
+    const bool pool_wanted = (P.flags & RT_F_POOL) || (getenv("RT_POOL") && atoi(getenv("RT_POOL")) != 0);
+    const bool pool = pool_wanted && !(P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) && (P.flags & RT_F_BVH) &&
+                      !((P.flags & RT_F_SPHERES) && c->sc.n_spheres > 0);
+    // the shortcut tree (rt_device.h) unless the call asks for the reference's walk, or counts it (RT_F_STATS)
+    const bool fast = c->sc.short_root >= 0 && !pool && !(P.flags & (RT_F_REFWALK | RT_F_VOLUME | RT_F_RAYMARCH)) && (P.flags & RT_F_BVH) &&
+                      (!want_stats || (P.flags & RT_F_SHORTCUT_STATS)) && !getenv("RT_REFWALK");
+    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true, fast);
     int rc = set_mega_lds(c, tc);
     if (rc != RT_OK) return rc;
     const size_t slots = (size_t)P.n_tiles * 64;  // pixels incl. the padding of edge tiles
@@ -2376,13 +2673,9 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         S = (S + 1) / 2;
     }
     const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.n_sub > 0, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
-                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN, tc.n_cached > c->sc.n_inner);
+                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN, !fast && tc.n_cached > c->sc.n_inner, fast);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
-    // the block-level ray pool (RT_F_POOL / RT_POOL=1): plain triangle scenes (no spheres, volume, ray marching, brute force)
-    const bool pool_wanted = (P.flags & RT_F_POOL) || (getenv("RT_POOL") && atoi(getenv("RT_POOL")) != 0);
-    const bool pool = pool_wanted && !(P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) && (P.flags & RT_F_BVH) &&
-                      !((P.flags & RT_F_SPHERES) && c->sc.n_spheres > 0);
     const PoolCfg pc = pool ? pool_cfg(c) : PoolCfg();
     const pool_fn pfn = pool_kernel_variant(want_stats, c->sc.n_sub > 0, c->sc.n_lights >= RT_LIGHTS_COOP_MIN);
     if (pool) occ = 1;
@@ -2573,7 +2866,7 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
-            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11];
+            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11]; stats->shortcut_rewalks = h[12];
         }
     }
     return RT_OK;

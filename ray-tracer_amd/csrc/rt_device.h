@@ -39,7 +39,21 @@ namespace rtd {
 //                                      leaf, bit2 = inside a sub-tree (its test is counted at the sub-tree's root);
 //                                      leafEnd = one past the last triangle of its reference leaf; id = the
 //                                      triangle's place in the reference's array (= its place here without sub-trees)
-//     q3 = unused
+//     q3 = (refLeafNode, 0, 0, 0)      the reference's leaf (node index) that holds the triangle
+// SHORTCUT TREE.  The reference's tree is what it is (mean splits, depth cap 16); its RESULT per ray is the triangle with
+// the smallest |fl(o + d t) - o|^2 among those it tests.  The fused path-parallel kernel first searches a surface-area tree
+// of this library's own, built at upload over the reference's non-empty leaves (each with its triangles or its sub-tree
+// below it; item q3.w = 2, padded boxes, the sub-trees' slack rule), remembering besides the best hit m (in leaf L) the
+// RIVAL: the smallest squared distance of a hit in another reference leaf (exact ties included).  When the search is over:
+//     bd = AABBIntersectDistance(ray, the reference's box of L), exactly as the reference evaluates it;
+//     certified  <=>  bd^2 < rival  and  m < rival  and  bd^2 <= m (1 + 1e-5) + slack / 2.
+// Reference boxes are nested (checked at upload) and the slab arithmetic is monotonic in the box, so every ancestor A of
+// L has bd(A)^2 <= bd^2; the reference prunes A only if bd(A)^2 >= its minDistSqr at that moment, which is 1e12 or the
+// squared distance of a hit from another leaf, i.e. >= rival > bd^2: the reference reaches L, tests all its triangles,
+// and nothing it finds elsewhere is as close as m.  Same triangle, same t.  The third condition keeps bd^2 inside what
+// the slack rule guarantees the shortcut walk has tested.  A ray that is not certified (a hit on an edge shared by two
+// leaves, coincident geometry) walks the reference's tree from the root; rays with a non-finite 1/d or from beyond
+// cull_far never try the shortcut.  RT_F_STATS counts the reference's walk and therefore walks it (RT_F_REFWALK).
 // LEAF SUB-TREES.  The reference tests EVERY triangle of a leaf, in array order, and a later triangle replaces the
 // hit only if strictly closer (main.cu:249-264): the leaf's result is the closest hit below the distance the ray
 // arrived with and, among equals, the one first in the array -- which does not depend on the order of the tests, and
@@ -56,6 +70,9 @@ namespace rtd {
 struct Scene {
     const float4* items;
     const int* tri_place;    // reference triangle id -> place in the item stream (callers' ids, test hooks)
+    const float4* ref_boxes; // the reference's node boxes as uploaded, (min, 0) (max, 0) per node: the shortcut certificate tests the hit's leaf
+    int short_root;          // item of the shortcut tree's root, RT_TRAV_DONE without one
+    int short_base;          // first item of the window [short_base, short_base + n_cached) the shortcut walk caches in LDS
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
@@ -181,13 +198,14 @@ struct Counters {
     uint32_t paths, rays, inner, leaf, tri, hits, texels, lights;
     // what the DEVICE really does (the eight above count the reference's walk, which a sub-tree root stands in for):
     // inner items visited (reference nodes and sub-tree nodes), of those served by the LDS node cache, triangle tests run
+    uint32_t rewalks;  // shortcut searches that were not certified and walked the reference's tree again
     uint32_t dev_inner, dev_cached, dev_tri, dev_lights;  // (dev_lights: light-triangle pdf tests really run, after the group culling)
 #ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
     unsigned long long prof[16];  // (8..15: lane census per iteration kind, rt_render_paths_kernel)   0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
 #endif
     __device__ __forceinline__ void clear() {
         paths = rays = inner = leaf = tri = hits = texels = lights = 0;
-        dev_inner = dev_cached = dev_tri = dev_lights = 0;
+        dev_inner = dev_cached = dev_tri = dev_lights = rewalks = 0;
 #ifdef RT_CYCLE_PROF
         for (int i = 0; i < 16; i++) prof[i] = 0;
 #endif
@@ -368,6 +386,8 @@ struct Trav {
     float invD2;  // 1 / |d|^2, a little up: the reference compares t^2 of a box with |d t|^2 of a hit (equal for unit directions)
     __device__ __forceinline__ void set_min(float m) { minD2 = m; subLim = (m * 1.00002f + slack) * invD2; }
     float minD2;  // minDistSqr, main.cu:223
+    float rival;  // shortcut walk: smallest squared distance of a hit in another reference leaf than the best one's; < 0 = this search walks the reference's tree
+    int bestLeaf; // shortcut walk: leafEnd of the best hit (names its reference leaf), -1 before the first hit
     float hitT;   // ray parameter of the closest hit: its position o + d * hitT is formed again when the query is
                   // over (same operands, same operations as main.cu:66 -> same bits) instead of being carried along
     __device__ __forceinline__ f3 hit_pos() const { return o() + d * hitT; }
@@ -539,7 +559,7 @@ __device__ __forceinline__ bool tie_replaces(const Scene& sc, int heldPlace, flo
 }
 
 // One triangle test of the current leaf (main.cu:249-264) on the fetched item.
-template <bool STATS, bool SUB>
+template <bool STATS, bool SUB, bool FAST = false>
 __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, int item, float4 q0, float4 q1,
                                                float4 q2) {
     const int flags = __float_as_int(q2.y);
@@ -550,9 +570,15 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
         const f3 pos = o + t.d * ht;
         const float nd = len2(pos - o);
         if (nd < t.minD2 || (SUB && nd == t.minD2 && tie_replaces(sc, t.hitTri, q2, false))) {
+            if (FAST && __float_as_int(q2.z) != t.bestLeaf) {  // the hit it replaces (1e12 before the first) is from another leaf: a rival
+                t.rival = fminf(t.rival, t.minD2);
+                t.bestLeaf = __float_as_int(q2.z);
+            }
             t.set_min(nd);
             t.set_hit(ht, pos);
             t.hitTri = item - sc.n_inner;
+        } else if (FAST && __float_as_int(q2.z) != t.bestLeaf) {
+            t.rival = fminf(t.rival, nd);
         }
     }
     if (flags & 1) trav_pop(t, stk);
@@ -585,12 +611,13 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
 // (rt_render_paths_kernel): an iteration then executes the code of one kind only.
 __device__ __forceinline__ bool trav_at_inner(const Scene& sc, const Trav& t) { return (unsigned)t.cur < (unsigned)sc.n_inner; }
 
+// cache_base: the LDS holds items [cache_base, cache_base + n_cached) (0 except in the shortcut walk's kernel)
 template <bool STATS, bool SUB, bool ALL_CACHED = false>  // ALL_CACHED: every inner item is in the LDS (no other path compiled in)
-__device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached) {  // trav_at_inner(t)
+__device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached, int cache_base = 0) {  // trav_at_inner(t)
     float4 q0, q1, q2, q3;
-    if (ALL_CACHED || t.cur < n_cached) {
+    if (ALL_CACHED || (unsigned)(t.cur - cache_base) < (unsigned)n_cached) {
         if (STATS) cn.dev_cached++;
-        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
+        load_cached_item(t.cur - cache_base, n_cached, q0, q1, q2, q3);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
@@ -602,7 +629,7 @@ __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* s
 }
 
 // TLDS: a scene so small that its WHOLE item stream sits in the LDS cache (n_cached = inner items + triangles).
-template <bool STATS, bool SUB, bool TLDS = false>
+template <bool STATS, bool SUB, bool TLDS = false, bool FAST = false>
 __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int n_cached = 0) {  // a triangle or RT_TRAV_EMPTY
     if (t.cur == RT_TRAV_EMPTY) {
         if (STATS) cn.leaf++;
@@ -623,7 +650,29 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
     asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y),
                  "+v"(q2.z), "+v"(q2.w));
 #endif
-    visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
+    visit_triangle<STATS, SUB, FAST>(sc, t, stk, cn, t.cur, q0, q1, q2);
+}
+
+// Shortcut walk (see SHORTCUT TREE above).  short_begin: after trav_begin has tested the reference's root box, send the
+// search down the shortcut tree if this ray may use it.  short_certified: the search is over (t.cur == RT_TRAV_DONE);
+// true = the result stands (also: no hit at all -- the shortcut walk tests every triangle whose padded boxes the ray
+// reaches, so the reference finds none either --, or the search already was the reference's walk).
+__device__ __forceinline__ void short_begin(const Scene& sc, Trav& t) {
+    t.bestLeaf = -1;
+    if (t.cur != RT_TRAV_DONE && !t.axis_parallel && t.slack < INFINITY) {
+        t.cur = sc.short_root;
+        t.rival = 1e12f;
+    } else {
+        t.rival = -1.0f;
+    }
+}
+__device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t) {
+    if (t.rival < 0.0f || t.hitTri < 0) return true;
+    const int leaf = __float_as_int(sc.items[4 * ((size_t)sc.n_inner + t.hitTri) + 3].x);
+    const float4 mn = sc.ref_boxes[2 * (size_t)leaf], mx = sc.ref_boxes[2 * (size_t)leaf + 1];
+    const float bd = aabb_distance(t.o(), t.inv(), mk(mn.x, mn.y, mn.z), mk(mx.x, mx.y, mx.z));
+    const float bd2 = bd * bd;
+    return bd2 < t.rival && t.minD2 < t.rival && bd2 <= t.minD2 * 1.00001f + 0.5f * t.slack;
 }
 
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }

@@ -269,6 +269,63 @@ def test_image_matches_oracle_same_rng(ob, rt, gpu, scenes, name, size, spp, bou
         assert getattr(st, f) == getattr(ost, f), f
 
 
+@pytest.mark.parametrize("name,size,spp", [("scene.txt", 128, 16), ("scene2.txt", 96, 8), ("scene2_is.txt", 64, 4)])
+def test_shortcut_tree_gives_the_oracles_image(ob, rt, gpu, scenes, name, size, spp):
+    """The fused kernel's default walk: the shortcut tree first, the reference's tree for the rays whose result is not
+    certified (rt_device.h).  Raw sums as the oracle's bit for bit, with and without counters; every counter that does
+    not describe the walk itself is the oracle's; the walk visits fewer items than the reference's."""
+    sc = scenes(name)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=spp, width=size, height=size, max_bounces=6, flags=rt.F_DEFAULT)
+    o, ost = ob.render(sc, p, n_threads=8)
+    gpu.reset(); gpu.render(p)
+    assert np.array_equal(gpu.readback(), o)
+    q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.F_STATS | rt.F_SHORTCUT_STATS
+    gpu.reset(); st = gpu.render(q)
+    assert np.array_equal(gpu.readback(), o)
+    for f in ("paths", "rays", "hits", "texel_fetches", "light_tests"):
+        assert getattr(st, f) == getattr(ost, f), f
+    q.flags = p.flags | rt.F_STATS
+    gpu.reset(); ref = gpu.render(q)
+    assert np.array_equal(gpu.readback(), o) and ref.inner_visits == ost.inner_visits and ref.shortcut_rewalks == 0
+    print(f"{name}: inner items per ray {st.dev_inner_visits / st.rays:.1f} (reference's walk {ref.dev_inner_visits / ref.rays:.1f}), "
+          f"triangle tests {st.dev_tri_tests / st.rays:.2f} ({ref.dev_tri_tests / ref.rays:.2f}), rewalks {st.shortcut_rewalks} of {st.rays} rays")
+    assert st.dev_inner_visits < 0.8 * ref.dev_inner_visits
+    assert st.shortcut_rewalks < 0.02 * st.rays
+    q.flags = p.flags | rt.F_REFWALK
+    gpu.reset(); gpu.render(q)
+    assert np.array_equal(gpu.readback(), o)
+
+
+def test_shortcut_rewalks_on_coplanar_sheets(ob, rt, gpu, monkeypatch):
+    """Two differently triangulated sheets in ONE plane: every ray that lands on them has two hits a rounding error apart,
+    in different reference leaves, and the hit's flat leaf box is as far away as the hit itself -- which of the two the
+    reference keeps depends on its walk, so about half of these searches fail the certificate and walk the reference's
+    tree.  Same image as the oracle, and the rewalk counter says the path was taken."""
+    recs = []
+    def tri(a, b, c):
+        r = np.zeros(25, np.float32)
+        r[0:9] = np.concatenate([a, b, c]); r[9:18] = np.tile([0, 1, 0], 3); r[24] = 0.001
+        return r
+    for nx, nz in ((12, 12), (11, 13)):
+        xs, zs = np.linspace(-6, 6, nx + 1), np.linspace(2, -10, nz + 1)
+        for i in range(nx):
+            for j in range(nz):
+                a, b, c, d = [xs[i], -1, zs[j]], [xs[i + 1], -1, zs[j]], [xs[i + 1], -1, zs[j + 1]], [xs[i], -1, zs[j + 1]]
+                recs += [tri(a, b, c), tri(a, c, d)]
+    floor = rt.Material(); floor.type = 3; floor.color = 0xC0C0C0; floor.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(np.stack(recs), [floor], bvh_max_depth=16, bvh_min_tris=1)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=4, width=96, height=64, max_bounces=4, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_SHORTCUT_STATS)
+    p.cam.pos[:] = [0, 0.1, 1.5]; p.cam.rot[:] = [-0.35, 0, 0]
+    gpu.reset(); st = gpu.render(p); img = gpu.readback()
+    o, ost = ob.render(sc, p, n_threads=8)
+    assert np.array_equal(img, o)
+    assert (st.rays, st.hits) == (ost.rays, ost.hits) and ost.hits > 5000
+    print(f"coplanar sheets: {st.shortcut_rewalks} rewalks for {st.hits} hits")
+    assert st.shortcut_rewalks > 0.1 * st.hits
+
+
 def test_tonemapped_readback(ob, rt, gpu, scenes):
     sc = scenes("scene_cornellbox.txt")
     p = rt.default_params(sc.camera, spp=8, width=64, height=64, max_bounces=4)

@@ -37,7 +37,7 @@ def unpack(items, info):
                       np.stack([inner[:, 4], inner[:, 5], inner[:, 10], inner[:, 6], inner[:, 7], inner[:, 11]], 1)], 1)
     entries = as_int(inner[:, 12:14])
     third = as_int(inner[:, 14])
-    is_sub = as_int(inner[:, 15]) != 0
+    is_sub = as_int(inner[:, 15]) == 1                                 # (2 = a node of the shortcut tree)
     flags, leaf_end, ids = as_int(tri[:, 9]), as_int(tri[:, 10]), as_int(tri[:, 11])
     return boxes, entries, third, is_sub, flags, leaf_end, ids
 
@@ -74,7 +74,8 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
     assert np.array_equal(got[:, 0], placed[:, 0]) and np.array_equal(got[:, 1], placed[:, 1] - placed[:, 0])
     # reference nodes: boxes and ids as uploaded, children in the reference's A / B order
     ref_inner = [i for i in range(len(nodes)) if nodes[i]["child_a"] != -1]
-    by_ref = {int(third[k]): k for k in range(info.n_inner) if not is_sub[k]}
+    kind = as_int(items[:info.n_inner, 15])                            # 0 the reference's node, 1 sub-tree node, 2 shortcut node
+    by_ref = {int(third[k]): k for k in range(info.n_inner) if kind[k] == 0}
     assert sorted(by_ref) == ref_inner
     for i in ref_inner:
         for side, ch in enumerate((nodes[i]["child_a"], nodes[i]["child_b"])):
@@ -125,6 +126,43 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
     walk(info.root_entry, 0, False)
     assert (seen == 1).all()
     assert depth_seen <= info.depth <= 24
+    # the shortcut tree: every non-empty reference leaf hangs below it exactly once, with what the reference's tree has
+    # below that leaf (its first triangle or its sub-tree); padded boxes hold everything below them
+    assert info.n_short == (kind == 2).sum() > 0 and kind[info.short_root] == 2
+    assert info.short_base + 1 <= info.n_inner and info.short_base <= 512
+    leaf_entries = {}
+    for k in range(info.n_inner):
+        if kind[k] == 0:
+            for side, ch in enumerate((nodes[int(third[k])]["child_a"], nodes[int(third[k])]["child_b"])):
+                if nodes[ch]["child_a"] == -1 and nodes[ch]["tri_len"] > 0:
+                    leaf_entries[int(entries[k, side])] = ch
+    seen[:] = 0
+    depth_seen = 0
+    reached = []
+
+    def walk_short(entry, d):
+        nonlocal depth_seen
+        if entry in leaf_entries:
+            reached.append(entry)
+            return walk(entry, d, False)
+        assert entry < info.n_inner and kind[entry] == 2
+        below = []
+        for side in range(2):
+            got_below = walk_short(int(entries[entry, side]), d + 1)
+            pts = placed[got_below].reshape(-1, 3)
+            assert (boxes[entry, side, :3] <= pts.min(0) - 0.5 * info.box_pad).all()
+            assert (boxes[entry, side, 3:] >= pts.max(0) + 0.5 * info.box_pad).all()
+            below += got_below
+        return below
+
+    walk_short(info.short_root, 0)
+    assert (seen == 1).all() and sorted(reached) == sorted(leaf_entries)
+    assert depth_seen <= info.short_depth <= 32
+    leaf_of = as_int(items[info.n_inner:, 12])                        # every triangle names its reference leaf
+    for nd_i, nd in enumerate(nodes):
+        if nd["child_a"] == -1 and nd["tri_len"] > 0:
+            first, cnt = nd["tri_offs"] // 25, nd["tri_len"] // 25
+            assert (leaf_of[first:first + cnt] == nd_i).all()
     # triangles outside sub-trees stand at their reference place, first / last flags per reference leaf
     for nd in nodes:
         if nd["child_a"] == -1 and nd["tri_len"] > 0:
@@ -136,7 +174,7 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
                 assert flags[first] & 2 and flags[first + cnt - 1] & 1
 
 
-def trace_on_items(info, items, o, d):
+def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
     """One ray through the item stream the way csrc/rt_device.h does it, in float32."""
     o, d = o.astype(F), d.astype(F)
     with np.errstate(all="ignore"):
@@ -162,61 +200,88 @@ def trace_on_items(info, items, o, d):
         def cross(a, b):
             return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F)
 
-        min_d2, hit, hit_t = F(1e12), -1, F(0)
-        sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
-        stack, cur, eps = [], info.root_entry, F(1e-9)
-        while True:
-            if cur == EMPTY:
-                pass
-            elif cur < info.n_inner:
-                w = items[cur]
-                bA = np.array([w[0], w[1], w[8], w[2], w[3], w[9]], F)
-                bB = np.array([w[4], w[5], w[10], w[6], w[7], w[11]], F)
-                dA, dB = box_dist(bA), box_dist(bB)
-                dA, dB = dA * dA, dB * dB
-                eA, eB = int(as_int(w[12:13])[0]), int(as_int(w[13:14])[0])
-                lim = sub_lim if as_int(w[15:16])[0] != 0 else min_d2
-                near, far, d_near, d_far = (eA, eB, dA, dB) if dA < dB else (eB, eA, dB, dA)
-                if d_far < lim:
-                    stack.append(far)
-                if d_near < lim:
-                    cur = near
-                    continue
-            else:
-                w = items[cur]
-                v0, e1, e2 = w[0:3], w[3:6], w[6:9]
-                p = cross(d, e2)
-                det = dot(e1, p)
-                if not (det > -eps and det < eps):
-                    inv_det = F(1.0) / det
-                    s = o - v0
-                    u = inv_det * dot(s, p)
-                    if not (u < 0 or u > 1):
-                        q = cross(s, e1)
-                        v = inv_det * dot(d, q)
-                        if not (v < 0 or u + v > 1):
-                            t = inv_det * dot(e2, q)
-                            if t > eps:
-                                pos = o + d * t
-                                r = pos - o
-                                nd = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]
-                                tie = False
-                                if nd == min_d2 and hit >= 0:
-                                    held = items[info.n_inner + hit]
-                                    tie = as_int(held[10:11])[0] == as_int(w[10:11])[0] and as_int(w[11:12])[0] < as_int(held[11:12])[0]
-                                if nd < min_d2 or tie:
-                                    min_d2, hit, hit_t = nd, cur - info.n_inner, t
-                                    sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
-                if not (as_int(w[9:10])[0] & 1):
-                    cur += 1
-                    continue
-            if not stack:
-                break
-            cur = stack.pop()
+        def search(start, fast):
+            min_d2, hit, hit_t = F(1e12), -1, F(0)
+            rival, best_leaf = F(1e12), -1
+            sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
+            stack, cur, eps = [], start, F(1e-9)
+            while True:
+                if cur == EMPTY:
+                    pass
+                elif cur < info.n_inner:
+                    w = items[cur]
+                    bA = np.array([w[0], w[1], w[8], w[2], w[3], w[9]], F)
+                    bB = np.array([w[4], w[5], w[10], w[6], w[7], w[11]], F)
+                    dA, dB = box_dist(bA), box_dist(bB)
+                    dA, dB = dA * dA, dB * dB
+                    eA, eB = int(as_int(w[12:13])[0]), int(as_int(w[13:14])[0])
+                    lim = sub_lim if as_int(w[15:16])[0] != 0 else min_d2
+                    near, far, d_near, d_far = (eA, eB, dA, dB) if dA < dB else (eB, eA, dB, dA)
+                    if d_far < lim:
+                        stack.append(far)
+                    if d_near < lim:
+                        cur = near
+                        continue
+                else:
+                    w = items[cur]
+                    v0, e1, e2 = w[0:3], w[3:6], w[6:9]
+                    p = cross(d, e2)
+                    det = dot(e1, p)
+                    if not (det > -eps and det < eps):
+                        inv_det = F(1.0) / det
+                        s = o - v0
+                        u = inv_det * dot(s, p)
+                        if not (u < 0 or u > 1):
+                            q = cross(s, e1)
+                            v = inv_det * dot(d, q)
+                            if not (v < 0 or u + v > 1):
+                                t = inv_det * dot(e2, q)
+                                if t > eps:
+                                    pos = o + d * t
+                                    r = pos - o
+                                    nd = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]
+                                    tie = False
+                                    if nd == min_d2 and hit >= 0:
+                                        held = items[info.n_inner + hit]
+                                        tie = as_int(held[10:11])[0] == as_int(w[10:11])[0] and as_int(w[11:12])[0] < as_int(held[11:12])[0]
+                                    this_leaf = int(as_int(w[10:11])[0])
+                                    if nd < min_d2 or tie:
+                                        if this_leaf != best_leaf:
+                                            rival, best_leaf = np.fmin(rival, min_d2), this_leaf
+                                        min_d2, hit, hit_t = nd, cur - info.n_inner, t
+                                        sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
+                                    elif this_leaf != best_leaf:
+                                        rival = np.fmin(rival, nd)
+                    if not (as_int(w[9:10])[0] & 1):
+                        cur += 1
+                        continue
+                if not stack:
+                    break
+                cur = stack.pop()
+            return hit, min_d2, hit_t, rival
+
+        rewalked = False
+        if shortcut:                                                   # rt_device.h: short_begin, short_certified
+            root = nodes[0]
+            root_ok = box_dist(np.concatenate([root["bbox_min"], root["bbox_max"]]).astype(F)) <= F(1e12)
+            if not root_ok:
+                return -1, F(-1), False
+            usable = np.isfinite(inv).all() and np.isfinite(slack)
+            hit, min_d2, hit_t, rival = search(info.short_root if usable else info.root_entry, usable)
+            if usable and hit >= 0:
+                leaf = nodes[int(as_int(items[info.n_inner + hit][12:13])[0])]
+                bd = box_dist(np.concatenate([leaf["bbox_min"], leaf["bbox_max"]]).astype(F))
+                bd2 = bd * bd
+                if not (bd2 < rival and min_d2 < rival and bd2 <= min_d2 * F(1.00001) + F(0.5) * slack):
+                    rewalked = True
+                    hit, min_d2, hit_t, rival = search(info.root_entry, False)
+        else:
+            hit, min_d2, hit_t, rival = search(info.root_entry, False)
         if hit < 0:
-            return -1, F(-1)
+            return (-1, F(-1), rewalked) if shortcut else (-1, F(-1))
         r = (o + d * hit_t) - o
-        return int(as_int(items[info.n_inner + hit][11:12])[0]), np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], dtype=F)
+        out = int(as_int(items[info.n_inner + hit][11:12])[0]), np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], dtype=F)
+        return out + (rewalked,) if shortcut else out
 
 
 @pytest.mark.parametrize("seed,n,depth,coincident", [(11, 700, 3, False), (12, 1500, 16, False), (13, 150, 2, True)])
@@ -237,9 +302,64 @@ def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, 
     rays = np.concatenate([org, d], 1).astype(np.float32)
     prim, t = ob.trace_rays(sc, rays, rt.F_BVH)[:2]
     assert (prim >= 0).sum() > k // 3
+    nodes, rewalks = sc.nodes(), 0
+    assert info.n_short > 0
     for i in range(k):
         p, tt = trace_on_items(info, items, rays[i, :3], rays[i, 3:])
         assert p == prim[i] and (p < 0 or tt == t[i]), (i, p, prim[i], tt, t[i])
+        # the shortcut tree first, the reference's tree where the certificate does not hold: the same answer
+        p, tt, again = trace_on_items(info, items, rays[i, :3], rays[i, 3:], shortcut=True, nodes=nodes)
+        assert p == prim[i] and (p < 0 or tt == t[i]), ("shortcut", i, p, prim[i], tt, t[i], again)
+        rewalks += again
+    assert rewalks < k // 20, rewalks                                              # (coincident copies share a centroid, hence a leaf)
+
+
+def butterfly_scene(rt, seed, n):
+    """Pairs of triangles that are mirror images in the plane x = y and share the edge that lies in it.  Swapping x and y
+    maps every product and sum of the triangle test onto one with the same bits, so a ray inside that plane which meets
+    the shared edge gets exactly the same distance from both triangles (or misses both): an exact tie between two
+    triangles whose centroids, and reference leaves, differ."""
+    rng = np.random.default_rng(seed)
+    p, q = rng.uniform(-2, 2, (n, 2)), rng.uniform(-2, 2, (n, 2))                  # (x = y, z) of the edge's ends
+    r = rng.uniform(-2, 2, (n, 3))
+    r[:, 1] = r[:, 0] + rng.choice([-1, 1], n) * rng.uniform(0.3, 1.0, n)          # the third vertex, off the plane
+    P, Q = np.stack([p[:, 0], p[:, 0], p[:, 1]], 1), np.stack([q[:, 0], q[:, 0], q[:, 1]], 1)
+    a = np.stack([P, Q, r], 1)
+    b = np.stack([P, Q, r[:, [1, 0, 2]]], 1)
+    v = np.concatenate([a, b]).astype(np.float32)
+    t = np.zeros((2 * n, 25), np.float32)
+    t[:, 0:9] = v.reshape(2 * n, 9)
+    t[:, 9:18] = np.tile([0, 0, 1.0], (2 * n, 3))
+    m = rt.Material(); m.type = 3; m.color = 0x808080; m.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(t, [m], bvh_max_depth=16, bvh_min_tris=1)
+    k = 3 * n
+    w = rng.uniform(0.1, 0.9, (k, 1)).astype(np.float32)
+    edge = np.tile(np.arange(n), 3)
+    target = (P[edge] * w + Q[edge] * (1 - w)).astype(np.float32)
+    target[:, 1] = target[:, 0]
+    o2 = rng.uniform(-4, 4, (k, 2)).astype(np.float32)
+    org = np.stack([o2[:, 0], o2[:, 0], o2[:, 1]], 1)
+    d = target - org
+    d[:, 1] = d[:, 0]
+    return sc, np.concatenate([org, d], 1).astype(np.float32)
+
+
+def test_exact_ties_across_leaves_walk_the_reference_tree(ob, rt, monkeypatch):
+    """Which of two triangles at exactly the same distance the reference keeps depends on the order of ITS walk: the
+    shortcut walk must not decide that (rival == best fails the certificate) and the reference's tree is walked."""
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    sc, rays = butterfly_scene(rt, 21, 120)
+    info, items, _ = rt.device_layout(sc)
+    assert info.n_short > 0
+    prim, t = ob.trace_rays(sc, rays, rt.F_BVH)[:2]
+    nodes, rewalks, hits = sc.nodes(), 0, 0
+    leaf_of = as_int(items[info.n_inner:, 12])
+    for i in range(0, len(rays), 2):
+        p, tt, again = trace_on_items(info, items, rays[i, :3], rays[i, 3:], shortcut=True, nodes=nodes)
+        assert p == prim[i] and (p < 0 or tt == t[i]), (i, p, prim[i], tt, t[i], again)
+        rewalks += again
+        hits += p >= 0
+    assert hits > 60 and rewalks > 20, (hits, rewalks)
 
 
 @pytest.mark.parametrize("scale,dist", [(1e-3, 1.0), (1.0, 3e4), (1e3, 10.0), (30.0, 2e4)])
@@ -264,9 +384,12 @@ def test_float32_walk_at_extreme_scales(ob, rt, monkeypatch, scale, dist):
     rays = np.concatenate([org, d], 1).astype(np.float32)
     prim, tt = ob.trace_rays(sc, rays, rt.F_BVH)[:2]
     assert (prim >= 0).sum() > k // 10
+    nodes = sc.nodes()
     for i in range(k):
         p, td = trace_on_items(info, items, rays[i, :3], rays[i, 3:])
         assert p == prim[i] and (p < 0 or td == tt[i]), (i, p, prim[i])
+        p, td, _ = trace_on_items(info, items, rays[i, :3], rays[i, 3:], shortcut=True, nodes=nodes)
+        assert p == prim[i] and (p < 0 or td == tt[i]), ("shortcut", i, p, prim[i])
 
 
 def test_layout_errors_are_reported(rt):
