@@ -229,6 +229,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_REF_FRONT 512         // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
+#define RT_SHORT_RUNS_MAX (1 << 20)  // shortcut tree over the runs of the item stream up to this many, over the reference's leaves above
 #define RT_SHORT_SWEEP_MAX 2048  // shortcut tree: full surface-area sweep up to this many leaves per node, 32 bins above
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
@@ -1830,9 +1831,10 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      the reference's own walk must return the same triangle, and the ray walks the reference's tree if not.
     //      Needs the reference's boxes to be nested (child inside parent), as its builder makes them.
     struct ShortPrim { float b[6]; float c[3]; float cost; int node; };
-    struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(reference leaf node)
+    struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(reference leaf node, or first place of a run)
     std::vector<ShortNode> shorts;
     int short_root = -1, short_levels = 0, below_leaf = 0;
+    bool short_runs = false;
     for (int wi = 0; wi < n_workers; wi++) below_leaf = std::max(below_leaf, work[(size_t)wi].max_below_leaf);
     {
         bool want = nn > 1 && ntri >= sub_min_tris && !getenv("RT_NO_SHORTCUT");
@@ -1843,20 +1845,33 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 for (int k = 0; k < 3; k++)
                     if (!(s->nodes[ch].bbox_min[k] >= n.bbox_min[k] && s->nodes[ch].bbox_max[k] <= n.bbox_max[k])) want = false;
         }
+        // What hangs below the shortcut tree: the RUNS of the item stream -- triangles tested one after the other up to a
+        // 'last' flag: a sub-leaf, or a whole reference leaf without a sub-tree -- so that the walk never enters a sub-tree;
+        // in a scene with more than RT_SHORT_RUNS_MAX of them the reference's leaves with their sub-trees (a smaller build).
         std::vector<ShortPrim> prims;
         if (want) {
+            size_t n_runs = 0;
+            for (int p = 0; p < ntri; p++) n_runs += covered[(size_t)p] && (tflags[(size_t)p] & 1);
+            short_runs = n_runs <= (size_t)RT_SHORT_RUNS_MAX && !getenv("RT_SHORT_LEAVES");
             for (int i = 0; i < nn; i++) {
                 const rt_bvh_node& n = s->nodes[i];
                 if (n.child_a != -1 || n.tri_len == 0) continue;
                 const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-                ShortPrim p;
-                memcpy(p.b, kEmpty, sizeof(p.b));
-                for (int k = 0; k < cnt; k++) grow(p.b, at[(size_t)first + k]);
-                for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (p.b[k] + p.b[3 + k]);
-                p.cost = 1.0f + (float)std::min(cnt, 4);  // steps a ray spends below the leaf's box, roughly
-                p.node = i;
-                prims.push_back(p);
+                for (int k = 0; k < cnt;) {
+                    int len = cnt - k;
+                    if (short_runs)
+                        for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
+                    ShortPrim p;
+                    memcpy(p.b, kEmpty, sizeof(p.b));
+                    for (int j = 0; j < len; j++) grow(p.b, at[(size_t)first + k + j]);
+                    for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (p.b[c] + p.b[3 + c]);
+                    p.cost = short_runs ? (float)len : 1.0f + (float)std::min(len, 4);  // steps a ray spends below the box, roughly
+                    p.node = short_runs ? first + k : i;  // the run's first place, or the leaf's node
+                    prims.push_back(p);
+                    k += len;
+                }
             }
+            if (short_runs) below_leaf = 0;
         }
         const int np = (int)prims.size();
         int lg = 0;
@@ -2196,7 +2211,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
             w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
             w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
-            for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : entry_of(~nd.e[k]));
+            for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : (short_runs ? n_inner + ~nd.e[k] : entry_of(~nd.e[k])));
             w[14] = i2f(0);
             w[15] = i2f(2);
         }

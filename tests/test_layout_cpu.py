@@ -59,9 +59,12 @@ def test_presorted_sweep_builds_the_same_sub_trees(rt, monkeypatch, seed, n, dep
     assert np.array_equal(as_int(items_a), as_int(items_b)) and np.array_equal(places_a, places_b)
 
 
-@pytest.mark.parametrize("seed,n,depth", [(1, 900, 4), (2, 3000, 16), (3, 400, 1)])
-def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
+@pytest.mark.parametrize("seed,n,depth,by_leaves", [(1, 900, 4, False), (2, 3000, 16, False), (3, 400, 1, False), (1, 900, 4, True),
+                                                   (2, 3000, 16, True)])
+def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    if by_leaves:                                                      # the shortcut tree over whole reference leaves (huge scenes)
+        monkeypatch.setenv("RT_SHORT_LEAVES", "1")
     sc, _ = make_scene(rt, seed, n, depth)
     info, items, places = rt.device_layout(sc)
     boxes, entries, third, is_sub, flags, leaf_end, ids = unpack(items, info)
@@ -142,7 +145,13 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
 
     def walk_short(entry, d):
         nonlocal depth_seen
-        if entry in leaf_entries:
+        if entry >= info.n_inner and not by_leaves:                    # a run of triangles up to a 'last' flag
+            depth_seen = max(depth_seen, d)
+            run = leaf_run(entry - info.n_inner)
+            assert entry == info.n_inner or flags[entry - info.n_inner - 1] & 1
+            seen[run] += 1
+            return run
+        if entry in leaf_entries and by_leaves:
             reached.append(entry)
             return walk(entry, d, False)
         assert entry < info.n_inner and kind[entry] == 2
@@ -156,7 +165,7 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth):
         return below
 
     walk_short(info.short_root, 0)
-    assert (seen == 1).all() and sorted(reached) == sorted(leaf_entries)
+    assert (seen == 1).all() and (not by_leaves or sorted(reached) == sorted(leaf_entries))
     assert depth_seen <= info.short_depth <= 32
     leaf_of = as_int(items[info.n_inner:, 12])                        # every triangle names its reference leaf
     for nd_i, nd in enumerate(nodes):
@@ -284,9 +293,12 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
         return out + (rewalked,) if shortcut else out
 
 
-@pytest.mark.parametrize("seed,n,depth,coincident", [(11, 700, 3, False), (12, 1500, 16, False), (13, 150, 2, True)])
-def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, seed, n, depth, coincident):
+@pytest.mark.parametrize("seed,n,depth,coincident,by_leaves", [(11, 700, 3, False, False), (12, 1500, 16, False, False), (13, 150, 2, True, False),
+                                                               (11, 700, 3, False, True), (13, 150, 2, True, True)])
+def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, seed, n, depth, coincident, by_leaves):
     monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    if by_leaves:
+        monkeypatch.setenv("RT_SHORT_LEAVES", "1")
     sc, rng = make_scene(rt, seed, n, depth, coincident)
     info, items, _ = rt.device_layout(sc)
     assert info.n_sub > 0
