@@ -778,7 +778,8 @@ __global__ __launch_bounds__(RT_LOGIC_BLOCK) void rt_logic_kernel(Scene sc, Para
 #endif
 // dynamic LDS (rt_lds, declared in rt_device.h): [4 * n_cached node pieces][RT_TRACE_WAVES x stack_entries x 64 ints]
 
-template <bool STATS>
+// FAST: the searches go down the shortcut tree first (rt_device.h), as in rt_render_paths_kernel.
+template <bool STATS, bool FAST = false>
 __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc, const float4* __restrict__ rayq,
                                                                         const unsigned int* __restrict__ n_rays_ptr,
                                                                         unsigned int* __restrict__ cursor,
@@ -790,8 +791,9 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
     const int wave = threadIdx.x >> 6;
     const unsigned int n_rays = *n_rays_ptr;
     if ((unsigned long long)blockIdx.x * RT_TRACE_WAVES * 64 >= n_rays) return;  // no wave of this block has a first chunk
+    const int cache_base = FAST ? sc.short_base : 0;
     for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_TRACE_WAVES)  // item i>>2, piece i&3 (coalesced read)
-        rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[i];
+        rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[4 * (size_t)cache_base + i];
     int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     __syncthreads();
     const bool use_bvh = (flags & RT_F_BVH) != 0;
@@ -836,6 +838,7 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
                     slot = __float_as_int(r0.w);
                     if (STATS) { cn.clear(); tot.rays++; }
                     trav_begin(sc, t, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+                    if (FAST) short_begin(sc, t);
                     if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
                     has = true;
                 }
@@ -845,7 +848,12 @@ __global__ __launch_bounds__(64 * RT_TRACE_WAVES) void rt_trace_kernel(Scene sc,
         if (!__any(has)) break;  // nothing in flight: the queue is exhausted as well
 #pragma unroll
         for (int k = 0; k < RT_TRACE_STEPS; k++)  // (several steps before the next look at the queue)
-            if (has && t.cur != RT_TRAV_DONE) trav_step<STATS, true>(sc, t, stk, cn, n_cached);
+            if (has && t.cur != RT_TRAV_DONE) trav_step<STATS, true, FAST>(sc, t, stk, cn, n_cached, cache_base);
+        if (FAST && has && t.cur == RT_TRAV_DONE && !short_certified(sc, t)) {  // not certified: the reference's walk decides
+            if (STATS) tot.rewalks++;
+            trav_begin(sc, t, t.o(), t.d);
+            t.rival = -1.0f;
+        }
         if (has && t.cur == RT_TRAV_DONE) {  // query finished: spheres (main.cu:305-334), publish, free the lane
             int tri = t.hitTri;
             f3 hp = tri >= 0 ? t.hit_pos() : mk(0.f, 0.f, 0.f);
@@ -1852,7 +1860,9 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         if (want) {
             size_t n_runs = 0;
             for (int p = 0; p < ntri; p++) n_runs += covered[(size_t)p] && (tflags[(size_t)p] & 1);
-            short_runs = n_runs <= (size_t)RT_SHORT_RUNS_MAX && !getenv("RT_SHORT_LEAVES");
+            size_t runs_max = RT_SHORT_RUNS_MAX;
+            if (const char* e = getenv("RT_SHORT_RUNS_MAX")) runs_max = (size_t)atoll(e);  // experiments only
+            short_runs = n_runs <= runs_max && !getenv("RT_SHORT_LEAVES");
             for (int i = 0; i < nn; i++) {
                 const rt_bvh_node& n = s->nodes[i];
                 if (n.child_a != -1 || n.tri_len == 0) continue;
@@ -2546,10 +2556,16 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     return t;
 }
 
+// rt_trace_rays / rt_trace_rays_noalloc: the shortcut tree unless the caller asks for the reference's walk or brute force
+bool trace_uses_shortcut(rt_context* c, uint32_t flags) {
+    return c->sc.short_root >= 0 && (flags & RT_F_BVH) && !(flags & RT_F_REFWALK) && !getenv("RT_REFWALK");
+}
+
 int set_trace_lds(rt_context* c, const TraceCfg& t) {
     if ((size_t)c->trace_lds_set >= t.lds_bytes) return RT_OK;
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_trace_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     HIP_TRY(c, hipFuncSetAttribute((const void*)rt_trace_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
+    HIP_TRY(c, hipFuncSetAttribute((const void*)rt_trace_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     c->trace_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
@@ -2986,12 +3002,18 @@ int rt_trace_rays(rt_context* c, const float* org_dir, size_t n, uint32_t flags,
     const unsigned int hn[2] = {(unsigned int)n, 0u};
     HIP_TRY(c, hipMemcpyAsync(d_n, hn, sizeof(hn), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_cnt, 0, n * 12, c->stream));
-    const TraceCfg tc = trace_cfg(c);
+    // per-ray visit counts describe the reference's walk: only then (or on request) is it walked for every ray
+    const bool fast = trace_uses_shortcut(c, flags) && !counts;
+    const TraceCfg tc = trace_cfg(c, RT_TRACE_WAVES, false, fast);
     rc = set_trace_lds(c, tc);
     if (rc != RT_OK) return rc;
     // the same persistent kernel the renderer uses (with refill), restricted to closest hit (+ spheres if asked)
-    hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,
-                       flags, d_cnt, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
+    if (fast)
+        hipLaunchKernelGGL((rt_trace_kernel<false, true>), dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, d_n, d_n + 1,
+                           d_hits, flags, (int*)nullptr, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
+    else
+        hipLaunchKernelGGL(rt_trace_kernel<true>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, d_n, d_n + 1, d_hits,
+                           flags, d_cnt, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
     hipLaunchKernelGGL(rt_hitinfo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, d_rays, d_hits, n, d_prim,
                        d_t, d_pos, d_nrm);
     HIP_TRY(c, hipGetLastError());
@@ -3020,14 +3042,19 @@ int rt_trace_rays_noalloc(rt_context* c, const float* dev_org_dir, size_t n, uin
     unsigned int* ctl = (unsigned int*)base;
     float4* d_q = (float4*)(base + RT_NOALLOC_CTL_BYTES);
     float4* d_hits = (float4*)(base + RT_NOALLOC_CTL_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * 32);
-    const TraceCfg tc = trace_cfg(c);
+    const bool fast = trace_uses_shortcut(c, flags);
+    const TraceCfg tc = trace_cfg(c, RT_TRACE_WAVES, false, fast);
     int rc = set_trace_lds(c, tc);  // (a function attribute, set once per context: no allocation)
     if (rc != RT_OK) return rc;
     // the queue and the control words are rewritten for every call (the array keeps the previous call's contents);
     // hit records are written for every ray of this call before rt_hitinfo_kernel reads them
     hipLaunchKernelGGL(rt_fill_queue_ctl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_org_dir, n, d_q, ctl);
-    hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, ctl, ctl + 1, d_hits,
-                       flags, (int*)nullptr, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
+    if (fast)
+        hipLaunchKernelGGL((rt_trace_kernel<false, true>), dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, ctl, ctl + 1,
+                           d_hits, flags, (int*)nullptr, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
+    else
+        hipLaunchKernelGGL(rt_trace_kernel<false>, dim3(tc.grid), dim3(64 * RT_TRACE_WAVES), tc.lds_bytes, c->stream, c->sc, d_q, ctl, ctl + 1, d_hits,
+                           flags, (int*)nullptr, (unsigned long long*)nullptr, tc.n_cached, tc.stack_entries);
     hipLaunchKernelGGL(rt_hitinfo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->sc, dev_org_dir, d_hits, n, dev_prim_id,
                        dev_t, dev_hit_pos, dev_normal3);
     HIP_TRY(c, hipGetLastError());

@@ -588,23 +588,23 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
 // ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit or one
 // triangle test of the current leaf.  All lanes of the wave share the four item loads, whatever kind
 // of item each of them holds.
-template <bool STATS, bool SUB>
-__device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached = 0) {
+template <bool STATS, bool SUB, bool FAST = false>
+__device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached = 0, int cache_base = 0) {
     if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
         if (STATS) cn.leaf++;
         trav_pop(t, stk);
         return;
     }
     float4 q0, q1, q2, q3;
-    if (t.cur < n_cached) {
+    if ((unsigned)(t.cur - cache_base) < (unsigned)n_cached) {
         if (STATS) cn.dev_cached++;
-        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);
+        load_cached_item(t.cur - cache_base, n_cached, q0, q1, q2, q3);
     } else {
         const float4* w = sc.items + 4 * (size_t)t.cur;
         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
     }
     if (t.cur < sc.n_inner) visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
-    else visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
+    else visit_triangle<STATS, SUB, FAST>(sc, t, stk, cn, t.cur, q0, q1, q2);
 }
 
 // The two kinds of step on their own, for schedulers that run them in separate wave-uniform phases

@@ -50,6 +50,9 @@ def check_hits(ob, rt, gpu, scene, rays, flags=None):
     assert np.all(np.abs(gn[hit] - on[hit]) <= 1e-5)
     # same visit order => same per-ray node/triangle counts
     assert np.array_equal(gc, oc)
+    # without per-ray counts the query goes down the shortcut tree first (where the scene has one): same ids, same bits
+    fp, ft, fpos, fn = gpu.trace_rays(rays, flags)[:4]
+    assert np.array_equal(fp, gp) and np.array_equal(ft, gt) and np.array_equal(fpos, gpos) and np.array_equal(fn, gn)
     return hit.mean()
 
 

@@ -13,6 +13,7 @@ n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 gpu = rt.Renderer(0)
 bad = 0
+rewalks = short_rays = 0
 t0 = time.time()
 for it in range(n_scenes):
     seed = seed0 + it
@@ -27,17 +28,19 @@ for it in range(n_scenes):
     p.seed = int(rng.integers(0, 1 << 31)); p.sample_begin = int(rng.integers(0, 1000))
     o, ost = ob.render(sc, p, n_threads=16)
     modes = ["megakernel", "pool"] + (["lockstep", "wavefront"] if it % 5 == 0 and not (flags & rt.F_VOLUME) else [])
-    for mode in modes:
-        q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.MODE_FLAGS[mode]
+    for mode in modes + ["shortcut"]:
+        q = rt.RenderParams.from_buffer_copy(p)
+        q.flags |= rt.MODE_FLAGS["megakernel"] | rt.F_SHORTCUT_STATS if mode == "shortcut" else rt.MODE_FLAGS[mode]
         gpu.reset(); st = gpu.render(q)
         same = np.array_equal(gpu.readback(), o)
-        cnt = [st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits, st.texel_fetches, st.light_tests] == \
-              [ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits, ost.texel_fetches, ost.light_tests]
+        walk = [] if mode == "shortcut" else ["inner_visits", "leaf_visits", "tri_tests"]   # (the shortcut walk's own visits are not the reference's)
+        cnt = all(getattr(st, f) == getattr(ost, f) for f in ["rays", "hits", "texel_fetches", "light_tests"] + walk)
+        rewalks += st.shortcut_rewalks; short_rays += st.rays if mode == "shortcut" else 0
         if not (same and cnt):
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} lights {len(sc.lights())} tris {sc.n_tris} image {same} counters {cnt}", flush=True)
     if it % 10 == 9:
         print(f"{it + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 gpu.close()
-print("render fuzz done:", n_scenes, "scenes,", bad, "mismatches")
+print("render fuzz done:", n_scenes, "scenes,", bad, "mismatches;", rewalks, "shortcut rewalks in", short_rays, "rays")
 sys.exit(1 if bad else 0)
