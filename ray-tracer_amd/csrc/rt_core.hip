@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_REF_FRONT 512         // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
 #define RT_SHORT_RUNS_MAX (1 << 20)  // shortcut tree over the runs of the item stream up to this many, over the reference's leaves above
-#define RT_SHORT_SWEEP_MAX 2048  // shortcut tree: full surface-area sweep up to this many leaves per node, 32 bins above
+#define RT_SHORT_SWEEP_MAX 64    // shortcut tree: full surface-area sweep up to this many leaves per node, 32 bins above
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
 #ifndef RT_INNER_STEPS
@@ -1530,6 +1530,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         std::vector<unsigned char> side;
         std::vector<float> suffix;
         std::vector<std::pair<int, int>> roots;  // (leaf node, root in subs)
+        std::vector<int> boxed;                  // candidate leaves in the order they were built ...
+        std::vector<float> boxes;                // ... and the padded box of each one's triangles (6 floats)
         int deepest = 0;
         int leaf_deepest = 0, max_below_leaf = 0;  // deepest level of the sub-tree being built; most levels any sub-tree adds below its leaf
     };
@@ -1784,6 +1786,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 float box[6];
                 w.leaf_deepest = depth[i];
                 const int root = build_sub(build_sub, w, first, first + cnt, depth[i], box, true);
+                w.boxed.push_back(i);
+                w.boxes.insert(w.boxes.end(), box, box + 6);
                 if (root >= 0) {
                     w.subs[(size_t)root].cnt = cnt;
                     w.roots.push_back({i, root});
@@ -1832,6 +1836,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         }
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
+    timer.stage("sub-tree nodes merged");
     // ---- SHORTCUT TREE (rt_device.h): a surface-area tree of this library's own over the reference's non-empty LEAVES
     //      (each with whatever hangs below it: its triangles or its sub-tree), padded boxes, walked with the sub-trees'
     //      slack rule.  It finds the closest hit in fewer visits than the reference's mean-split tree; a per-ray
@@ -1858,31 +1863,68 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         // in a scene with more than RT_SHORT_RUNS_MAX of them the reference's leaves with their sub-trees (a smaller build).
         std::vector<ShortPrim> prims;
         if (want) {
-            size_t n_runs = 0;
-            for (int p = 0; p < ntri; p++) n_runs += covered[(size_t)p] && (tflags[(size_t)p] & 1);
             size_t runs_max = RT_SHORT_RUNS_MAX;
             if (const char* e = getenv("RT_SHORT_RUNS_MAX")) runs_max = (size_t)atoll(e);  // experiments only
-            short_runs = n_runs <= runs_max && !getenv("RT_SHORT_LEAVES");
-            for (int i = 0; i < nn; i++) {
-                const rt_bvh_node& n = s->nodes[i];
-                if (n.child_a != -1 || n.tri_len == 0) continue;
-                const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-                for (int k = 0; k < cnt;) {
-                    int len = cnt - k;
-                    if (short_runs)
-                        for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
-                    ShortPrim p;
-                    memcpy(p.b, kEmpty, sizeof(p.b));
-                    for (int j = 0; j < len; j++) grow(p.b, at[(size_t)first + k + j]);
-                    for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (p.b[c] + p.b[3 + c]);
-                    p.cost = short_runs ? (float)len : 1.0f + (float)std::min(len, 4);  // steps a ray spends below the box, roughly
-                    p.node = short_runs ? first + k : i;  // the run's first place, or the leaf's node
-                    prims.push_back(p);
-                    k += len;
+            std::vector<size_t> c_runs((size_t)n_workers_max + 1, 0), c_leaves((size_t)n_workers_max + 1, 0);
+            const int nr = par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {  // count per range of nodes, prefix, fill
+                size_t r = 0, l = 0;
+                for (size_t i = lo; i < hi; i++) {
+                    const rt_bvh_node& n = s->nodes[i];
+                    if (n.child_a != -1 || n.tri_len == 0) continue;
+                    const size_t first = (size_t)(n.tri_offs / RT_TRI_FLOATS), cnt = (size_t)(n.tri_len / RT_TRI_FLOATS);
+                    l++;
+                    for (size_t k = 0; k < cnt; k++) r += tflags[first + k] & 1;
                 }
+                c_runs[(size_t)wi + 1] = r;
+                c_leaves[(size_t)wi + 1] = l;
+            });
+            for (int wi = 0; wi < nr; wi++) { c_runs[(size_t)wi + 1] += c_runs[(size_t)wi]; c_leaves[(size_t)wi + 1] += c_leaves[(size_t)wi]; }
+            short_runs = c_runs[(size_t)nr] <= runs_max && !getenv("RT_SHORT_LEAVES");
+            const std::vector<size_t>& off = short_runs ? c_runs : c_leaves;
+            prims.resize(off[(size_t)nr]);
+            // boxes the sub-tree build has formed already (padded once; the shortcut builder pads again): a candidate leaf's
+            // and, through the sub-tree nodes, every sub-leaf's -- the triangles are not read again
+            std::vector<const float*> leaf_box((size_t)nn, nullptr);
+            for (const SubWork& w : work)
+                for (size_t k = 0; k < w.boxed.size(); k++) leaf_box[(size_t)w.boxed[k]] = &w.boxes[6 * k];
+            std::vector<int> run_src;  // place of a sub-leaf's first triangle -> 2 * sub node + side
+            if (short_runs && n_sub > 0) {
+                run_src.assign((size_t)ntri, -1);
+                par_ranges((size_t)n_sub, [&](int, size_t lo, size_t hi) {
+                    for (size_t j = lo; j < hi; j++)
+                        for (int k = 0; k < 2; k++)
+                            if (subs[j].e[k] < 0) run_src[(size_t)~subs[j].e[k]] = (int)(2 * j) + k;
+                });
             }
+            par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {
+                size_t o = off[(size_t)wi];
+                for (size_t i = lo; i < hi; i++) {
+                    const rt_bvh_node& n = s->nodes[i];
+                    if (n.child_a != -1 || n.tri_len == 0) continue;
+                    const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+                    const bool whole = !short_runs || sub_root[i] < 0;  // the leaf as one unit
+                    for (int k = 0; k < cnt;) {
+                        int len = cnt - k;
+                        if (!whole)
+                            for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
+                        ShortPrim& p = prims[o++];
+                        const float* known = whole ? leaf_box[i] : (run_src[(size_t)first + k] >= 0 ? subs[(size_t)(run_src[(size_t)first + k] >> 1)].box[run_src[(size_t)first + k] & 1] : nullptr);
+                        if (known) {
+                            memcpy(p.b, known, sizeof(p.b));
+                        } else {
+                            memcpy(p.b, kEmpty, sizeof(p.b));
+                            for (int j = 0; j < len; j++) grow(p.b, at[(size_t)first + k + j]);
+                        }
+                        for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (p.b[c] + p.b[3 + c]);
+                        p.cost = short_runs ? (float)len : 1.0f + (float)std::min(len, 4);  // steps a ray spends below the box, roughly
+                        p.node = short_runs ? first + k : (int)i;  // the run's first place, or the leaf's node
+                        k += len;
+                    }
+                }
+            });
             if (short_runs) below_leaf = 0;
         }
+        timer.stage("shortcut tree: leaves / runs and their boxes");
         const int np = (int)prims.size();
         int lg = 0;
         while ((1 << lg) < np) lg++;
@@ -1890,95 +1932,151 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         const int levels_max = std::min(RT_SHORT_STACK_MAX - below_leaf, lg + 8);
         if (np >= 2 && lg <= levels_max) {
             shorts.resize((size_t)np - 1);  // the node that splits [lo, hi) at mid is shorts[mid - 1]: no two nodes share a split point
-            std::vector<int> ids((size_t)np);
-            for (int k = 0; k < np; k++) ids[(size_t)k] = k;
             std::atomic<int> deepest_short{0};
-            auto union_box = [&](int lo, int hi, float* box) {
-                memcpy(box, kEmpty, 6 * sizeof(float));
-                for (int p = lo; p < hi; p++) {
-                    const float* b = prims[(size_t)ids[(size_t)p]].b;
-                    for (int c = 0; c < 3; c++) { box[c] = std::min(box[c], b[c]); box[3 + c] = std::max(box[3 + c], b[3 + c]); }
+            const int NB = 32;              // bins of the centroid range per axis
+            struct Bins { float bb[3][32][6], bw[3][32]; int bn[3][32]; float ub[6], cmn[3], cmx[3]; };
+            // A pass over prims[lo, hi) in fixed chunks of 2^16, the chunks' results folded in chunk order: the same result on
+            // any number of threads (the float sums included); big nodes only, where the recursion has few branches yet.
+            auto chunked = [&](int lo, int hi, auto&& init, auto&& one, auto&& fold, auto& total) {
+                const int CH = 1 << 16, n = hi - lo, nch = (n + CH - 1) / CH;
+                if (n < (1 << 18)) {
+                    init(total);
+                    for (int p = lo; p < hi; p++) one(total, prims[(size_t)p]);
+                    return;
                 }
+                std::vector<typename std::remove_reference<decltype(total)>::type> part((size_t)nch);
+                std::atomic<int> next{0};
+                auto run = [&] {
+                    for (int c; (c = next.fetch_add(1)) < nch;) {
+                        init(part[(size_t)c]);
+                        for (int p = lo + c * CH; p < std::min(hi, lo + (c + 1) * CH); p++) one(part[(size_t)c], prims[(size_t)p]);
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int wi = 1; wi < n_workers_max; wi++) th.emplace_back(run);
+                run();
+                for (auto& t : th) t.join();
+                init(total);
+                for (int c = 0; c < nch; c++) fold(total, part[(size_t)c]);
             };
-            // returns the entry of the node over ids[lo, hi) standing at level d (root: 0) and its padded box
+            auto less_on = [](int axis) {
+                return [axis](const ShortPrim& a, const ShortPrim& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.node < b.node); };
+            };
+            // returns the entry of the node over prims[lo, hi) standing at level d (root: 0) and its padded box
             auto build_short = [&](auto&& self, int lo, int hi, int d, float* box) -> int {
                 const int n = hi - lo;
-                union_box(lo, hi, box);
-                for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
                 int seen = deepest_short.load();
                 while (seen < d && !deepest_short.compare_exchange_weak(seen, d)) {}
-                if (n == 1) return ~prims[(size_t)ids[(size_t)lo]].node;
+                if (n == 1) {
+                    memcpy(box, prims[(size_t)lo].b, 6 * sizeof(float));
+                    for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
+                    return ~prims[(size_t)lo].node;
+                }
                 // a side may keep at most 2^(levels_max - d - 1) leaves: what is left of the levels can still hold them
                 const int room = levels_max - d - 1;
                 const int side_max = room >= 30 ? n : std::min(n, 1 << room);
                 const int k_lo = std::max(1, n - side_max), k_hi = std::min(n - 1, side_max);  // left = the first k, k in [k_lo, k_hi]
                 int best_axis = -1, best_k = -1;
                 float best = 3e38f;
-                std::vector<float> suffix;
-                auto by_axis = [&](int axis) {
-                    std::sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) {
-                        const float ca = prims[(size_t)a].c[axis], cb = prims[(size_t)b].c[axis];
-                        return ca < cb || (ca == cb && prims[(size_t)a].node < prims[(size_t)b].node);
-                    });
-                };
-                if (n <= RT_SHORT_SWEEP_MAX) {
-                    suffix.resize(2 * ((size_t)n + 1));
+                float cmn[3], cmx[3];
+                if (n <= RT_SHORT_SWEEP_MAX) {  // every split position along every axis
+                    float suffix[2 * (RT_SHORT_SWEEP_MAX + 1)];
+                    memcpy(box, kEmpty, 6 * sizeof(float));
+                    for (int k = 0; k < 3; k++) { cmn[k] = 3e38f; cmx[k] = -3e38f; }
+                    for (int p = lo; p < hi; p++) {
+                        const ShortPrim& pr = prims[(size_t)p];
+                        for (int c = 0; c < 3; c++) {
+                            box[c] = std::min(box[c], pr.b[c]); box[3 + c] = std::max(box[3 + c], pr.b[3 + c]);
+                            cmn[c] = std::min(cmn[c], pr.c[c]); cmx[c] = std::max(cmx[c], pr.c[c]);
+                        }
+                    }
                     for (int axis = 0; axis < 3; axis++) {
-                        by_axis(axis);
+                        std::sort(prims.begin() + lo, prims.begin() + hi, less_on(axis));
                         float bx[6], w = 0.f;
                         memcpy(bx, kEmpty, sizeof(bx));
                         for (int k = n - 1; k >= 1; k--) {
-                            const ShortPrim& p = prims[(size_t)ids[(size_t)(lo + k)]];
+                            const ShortPrim& p = prims[(size_t)(lo + k)];
                             for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], p.b[c]); bx[3 + c] = std::max(bx[3 + c], p.b[3 + c]); }
                             w += p.cost;
-                            suffix[2 * (size_t)k] = half_area(bx);
-                            suffix[2 * (size_t)k + 1] = w;
+                            suffix[2 * k] = half_area(bx);
+                            suffix[2 * k + 1] = w;
                         }
                         memcpy(bx, kEmpty, sizeof(bx));
                         w = 0.f;
                         for (int k = 1; k < n; k++) {
-                            const ShortPrim& p = prims[(size_t)ids[(size_t)(lo + k - 1)]];
+                            const ShortPrim& p = prims[(size_t)(lo + k - 1)];
                             for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], p.b[c]); bx[3 + c] = std::max(bx[3 + c], p.b[3 + c]); }
                             w += p.cost;
                             if (k < k_lo || k > k_hi) continue;
-                            const float cst = half_area(bx) * w + suffix[2 * (size_t)k] * suffix[2 * (size_t)k + 1];
+                            const float cst = half_area(bx) * w + suffix[2 * k] * suffix[2 * k + 1];
                             if (cst < best) { best = cst; best_axis = axis; best_k = k; }
                         }
                     }
-                    if (best_axis >= 0 && best_axis != 2) by_axis(best_axis);
+                    if (best_axis >= 0 && best_axis != 2) std::sort(prims.begin() + lo, prims.begin() + hi, less_on(best_axis));
                 } else {  // 32 bins of the centroid range per axis; the leaves are then partitioned, not sorted
-                    const int NB = 32;
-                    float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
-                    for (int p = lo; p < hi; p++)
-                        for (int k = 0; k < 3; k++) {
-                            const float cc = prims[(size_t)ids[(size_t)p]].c[k];
-                            cmn[k] = std::min(cmn[k], cc);
-                            cmx[k] = std::max(cmx[k], cc);
-                        }
-                    int best_bin = -1;
+                    struct Ext { float ub[6], cmn[3], cmx[3]; } ext;
+                    chunked(lo, hi,
+                            [&](Ext& e) { memcpy(e.ub, kEmpty, sizeof(e.ub)); for (int k = 0; k < 3; k++) { e.cmn[k] = 3e38f; e.cmx[k] = -3e38f; } },
+                            [&](Ext& e, const ShortPrim& pr) {
+                                for (int c = 0; c < 3; c++) {
+                                    e.ub[c] = std::min(e.ub[c], pr.b[c]); e.ub[3 + c] = std::max(e.ub[3 + c], pr.b[3 + c]);
+                                    e.cmn[c] = std::min(e.cmn[c], pr.c[c]); e.cmx[c] = std::max(e.cmx[c], pr.c[c]);
+                                }
+                            },
+                            [&](Ext& e, const Ext& q) {
+                                for (int c = 0; c < 3; c++) {
+                                    e.ub[c] = std::min(e.ub[c], q.ub[c]); e.ub[3 + c] = std::max(e.ub[3 + c], q.ub[3 + c]);
+                                    e.cmn[c] = std::min(e.cmn[c], q.cmn[c]); e.cmx[c] = std::max(e.cmx[c], q.cmx[c]);
+                                }
+                            },
+                            ext);
+                    memcpy(box, ext.ub, sizeof(ext.ub));
+                    memcpy(cmn, ext.cmn, sizeof(cmn));
+                    memcpy(cmx, ext.cmx, sizeof(cmx));
+                    float scale[3];
+                    for (int k = 0; k < 3; k++) scale[k] = cmx[k] > cmn[k] ? (float)NB / (cmx[k] - cmn[k]) : 0.f;
                     auto bin_of = [&](const ShortPrim& p, int axis) {
-                        const float wdt = cmx[axis] - cmn[axis];
-                        const int b = (int)((p.c[axis] - cmn[axis]) / wdt * (float)NB);
-                        return std::min(NB - 1, std::max(0, b));
+                        return std::min(NB - 1, std::max(0, (int)((p.c[axis] - cmn[axis]) * scale[axis])));
                     };
+                    std::unique_ptr<Bins> bins(new Bins);
+                    chunked(lo, hi,
+                            [&](Bins& B) {
+                                for (int a = 0; a < 3; a++)
+                                    for (int b = 0; b < NB; b++) { memcpy(B.bb[a][b], kEmpty, 6 * sizeof(float)); B.bw[a][b] = 0.f; B.bn[a][b] = 0; }
+                            },
+                            [&](Bins& B, const ShortPrim& pr) {
+                                for (int a = 0; a < 3; a++) {
+                                    const int b = bin_of(pr, a);
+                                    float* bx = B.bb[a][b];
+                                    for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], pr.b[c]); bx[3 + c] = std::max(bx[3 + c], pr.b[3 + c]); }
+                                    B.bw[a][b] += pr.cost;
+                                    B.bn[a][b]++;
+                                }
+                            },
+                            [&](Bins& B, const Bins& Q) {
+                                for (int a = 0; a < 3; a++)
+                                    for (int b = 0; b < NB; b++) {
+                                        for (int c = 0; c < 3; c++) {
+                                            B.bb[a][b][c] = std::min(B.bb[a][b][c], Q.bb[a][b][c]);
+                                            B.bb[a][b][3 + c] = std::max(B.bb[a][b][3 + c], Q.bb[a][b][3 + c]);
+                                        }
+                                        B.bw[a][b] += Q.bw[a][b];
+                                        B.bn[a][b] += Q.bn[a][b];
+                                    }
+                            },
+                            *bins);
+                    int best_bin = -1;
                     for (int axis = 0; axis < 3; axis++) {
                         if (!(cmx[axis] > cmn[axis])) continue;
-                        float bb[NB][6], bw[NB];
-                        int bn[NB];
-                        for (int b = 0; b < NB; b++) { memcpy(bb[b], kEmpty, sizeof(bb[b])); bw[b] = 0.f; bn[b] = 0; }
-                        for (int p = lo; p < hi; p++) {
-                            const ShortPrim& pr = prims[(size_t)ids[(size_t)p]];
-                            const int b = bin_of(pr, axis);
-                            for (int c = 0; c < 3; c++) { bb[b][c] = std::min(bb[b][c], pr.b[c]); bb[b][3 + c] = std::max(bb[b][3 + c], pr.b[3 + c]); }
-                            bw[b] += pr.cost;
-                            bn[b]++;
-                        }
-                        float ra[NB], rw[NB], bx[6], w = 0.f;
+                        const auto& bb = bins->bb[axis];
+                        const float* bw = bins->bw[axis];
+                        const int* bn = bins->bn[axis];
+                        float ra[32], rw[32], bx[6], w = 0.f;
                         memcpy(bx, kEmpty, sizeof(bx));
                         for (int b = NB - 1; b >= 1; b--) {
                             for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], bb[b][c]); bx[3 + c] = std::max(bx[3 + c], bb[b][3 + c]); }
                             w += bw[b];
-                            ra[b] = bn[b] || w > 0.f ? half_area(bx) : 0.f;
+                            ra[b] = half_area(bx);
                             rw[b] = w;
                         }
                         memcpy(bx, kEmpty, sizeof(bx));
@@ -1995,27 +2093,21 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     }
                     if (best_axis >= 0) {
                         const int axis = best_axis, bsplit = best_bin;
-                        std::stable_partition(ids.begin() + lo, ids.begin() + hi, [&](int a) { return bin_of(prims[(size_t)a], axis) < bsplit; });
+                        std::partition(prims.begin() + lo, prims.begin() + hi, [&](const ShortPrim& a) { return bin_of(a, axis) < bsplit; });
                     }
                 }
+                for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
                 if (best_axis < 0) {  // no admissible surface-area split (or every centroid in one place): halves along the widest axis
-                    float cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
-                    for (int p = lo; p < hi; p++)
-                        for (int k = 0; k < 3; k++) {
-                            const float cc = prims[(size_t)ids[(size_t)p]].c[k];
-                            cmn[k] = std::min(cmn[k], cc);
-                            cmx[k] = std::max(cmx[k], cc);
-                        }
                     int axis = 0;
                     for (int k = 1; k < 3; k++)
                         if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-                    by_axis(axis);
                     best_k = n / 2;
+                    std::nth_element(prims.begin() + lo, prims.begin() + lo + best_k, prims.begin() + hi, less_on(axis));
                 }
                 const int mid = lo + best_k;
                 float ba[6], bb2[6];
                 int ea, eb;
-                if (n >= (1 << 14) && d < 4) {  // the big halves on two host threads (disjoint ranges of ids and of shorts)
+                if (n >= (1 << 14) && d < 4) {  // the big halves on two host threads (disjoint ranges of prims and of shorts)
                     int ea_t = 0;
                     std::thread th([&] { ea_t = self(self, lo, mid, d + 1, ba); });
                     eb = self(self, mid, hi, d + 1, bb2);
