@@ -227,14 +227,17 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_SUB_GAIN 1.0f        // ... by this factor at least,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
-#define RT_REF_FRONT 512         // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
+#define RT_REF_FRONT 1024        // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
 #define RT_SHORT_RUNS_MAX (1 << 20)  // shortcut tree over the runs of the item stream up to this many, over the reference's leaves above
-#define RT_SHORT_SWEEP_MAX 64    // shortcut tree: full surface-area sweep up to this many leaves per node, 32 bins above
+#define RT_SHORT_SWEEP_MAX 2048  // shortcut tree: full surface-area sweep up to this many leaves per node (64 in trees over more than 2^18: build time), 32 bins above
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
 #define RT_SUB_SWEEP_MAX 4096   // full surface-area sweep up to this many triangles, median splits above (bounds the build time)
 #ifndef RT_INNER_STEPS
 #define RT_INNER_STEPS 4  // inner-node visits per vote (a vote costs about a tenth of a visit; 1 / 2 / 3 / 4 / 6 / 8: 31.9 / 30.3 / 30.0 / 29.8 / 31.3 / 30.6 ms)
+#endif
+#ifndef RT_INNER_STEPS_SHORT
+#define RT_INNER_STEPS_SHORT 3  // ... on the shortcut walk (fewer, less alike walks: 2 / 3 / 4 / 6: 23.5 / 23.0 / 23.4 / 23.45 ms; the Cornell box, which has none, loses 6 % with 3)
 #endif
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 RT_PROF_LANE(cn, 1);
                 trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
-                for (int k = 1; k < RT_INNER_STEPS; k++)  // (more visits before the next vote: a vote costs a tenth of a step)
+                for (int k = 1; k < (FAST ? RT_INNER_STEPS_SHORT : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
                     if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
             }
         }
@@ -1934,6 +1937,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             shorts.resize((size_t)np - 1);  // the node that splits [lo, hi) at mid is shorts[mid - 1]: no two nodes share a split point
             std::atomic<int> deepest_short{0};
             const int NB = 32;              // bins of the centroid range per axis
+            const int short_sweep_max = np <= (1 << 18) ? RT_SHORT_SWEEP_MAX : 64;
             struct Bins { float bb[3][32][6], bw[3][32]; int bn[3][32]; float ub[6], cmn[3], cmx[3]; };
             // A pass over prims[lo, hi) in fixed chunks of 2^16, the chunks' results folded in chunk order: the same result on
             // any number of threads (the float sums included); big nodes only, where the recursion has few branches yet.
@@ -1979,7 +1983,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 int best_axis = -1, best_k = -1;
                 float best = 3e38f;
                 float cmn[3], cmx[3];
-                if (n <= RT_SHORT_SWEEP_MAX) {  // every split position along every axis
+                if (n <= short_sweep_max) {  // every split position along every axis
                     float suffix[2 * (RT_SHORT_SWEEP_MAX + 1)];
                     memcpy(box, kEmpty, 6 * sizeof(float));
                     for (int k = 0; k < 3; k++) { cmn[k] = 3e38f; cmx[k] = -3e38f; }
@@ -2200,12 +2204,12 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         // Without a shortcut tree: reference and sub-tree nodes in ONE order by area (what the reference's walk meets most).
         // With one the kernels cache one of two windows of the item stream: the reference's walk items [0, n_cached) --
         // RT_REF_FRONT of its own biggest nodes, then the window below --, the shortcut walk items [short_base, short_base +
-        // n_cached): the biggest shortcut and sub-tree nodes, which is all it visits.
+        // n_cached): the biggest shortcut nodes (and sub-tree nodes, where it enters sub-trees), which is all it visits.
         std::vector<Key> big;
         if (n_short > 0 && front) {
             big = select(1, std::min<size_t>(RT_REF_FRONT, (size_t)n_top));
             short_base = (int)big.size();
-            const std::vector<Key> rest = select(2 | 4, front);
+            const std::vector<Key> rest = select(short_runs ? 4 : 2 | 4, front);  // (over runs the shortcut walk never enters a sub-tree)
             big.insert(big.end(), rest.begin(), rest.end());
         } else {
             big = select(1 | 2 | 4, front);

@@ -132,7 +132,7 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     # the shortcut tree: every non-empty reference leaf hangs below it exactly once, with what the reference's tree has
     # below that leaf (its first triangle or its sub-tree); padded boxes hold everything below them
     assert info.n_short == (kind == 2).sum() > 0 and kind[info.short_root] == 2
-    assert info.short_base + 1 <= info.n_inner and info.short_base <= 512
+    assert info.short_base + 1 <= info.n_inner and info.short_base <= 1024
     leaf_entries = {}
     for k in range(info.n_inner):
         if kind[k] == 0:
