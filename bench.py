@@ -294,6 +294,7 @@ def main():
             "inner_items_visited": int(st_dev.dev_inner_visits), "of_those_from_lds": int(st_dev.dev_lds_inner_visits),
             "triangle_tests_run": int(st_dev.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
             "reference_walk_inner_visits": int(st_counts.inner_visits), "shortcut_rewalks": int(st_dev.shortcut_rewalks),
+            "scene_has_shortcut_tree": bool(st_dev.dev_inner_visits != st_counts.dev_inner_visits or st_dev.shortcut_rewalks),
             "light_tests_run": int(st_dev.dev_light_tests), "reference_walk_light_tests": int(st_counts.light_tests),
             "lds_GBps": round(lds_b / launch_s / 1e9, 1), "lds_peak_GBps": 150000.0,
             "l2_GBps": round(l2_b / launch_s / 1e9, 1), "l2_peak_GBps": 34500.0}
