@@ -404,6 +404,24 @@ def test_float32_walk_at_extreme_scales(ob, rt, monkeypatch, scale, dist):
         assert p == prim[i] and (p < 0 or td == tt[i]), ("shortcut", i, p, prim[i])
 
 
+def test_no_shortcut_tree_over_boxes_that_are_not_nested(rt, monkeypatch):
+    """The certificate of the shortcut walk relies on every reference box lying inside its parent's (rt_device.h).  The
+    reference's builder makes them so; a caller's tree that does not gets no shortcut tree (and is walked as it is)."""
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    sc, _ = make_scene(rt, 8, 600, 6)
+    assert rt.device_layout(sc)[0].n_short > 0
+    child = sc.desc.nodes[sc.desc.nodes[0].child_a]
+    keep = child.bbox_max[1]
+    child.bbox_max[1] = sc.desc.nodes[0].bbox_max[1] + 1.0            # sticks out of the root's box
+    try:
+        info = rt.device_layout(sc)[0]
+        assert info.n_short == 0 and info.short_root == -1 and info.short_depth == 0 and info.n_sub > 0
+    finally:
+        child.bbox_max[1] = keep
+    monkeypatch.setenv("RT_NO_SHORTCUT", "1")
+    assert rt.device_layout(sc)[0].n_short == 0
+
+
 def test_layout_errors_are_reported(rt):
     sc, _ = make_scene(rt, 5, 40, 3)
     sc.desc.n_tri_floats -= 1

@@ -17,7 +17,7 @@ bad = 0
 t_start = time.time()
 for it in range(n_scenes):
     rng = np.random.default_rng(seed0 + it)
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 6)
     n = int(rng.integers(30, 6000))
     scale = float(10.0 ** rng.uniform(-3, 3))
     if kind == 0:      # soup
@@ -29,10 +29,27 @@ for it in range(n_scenes):
         ax = rng.integers(0, 3, n)
         e1 = np.eye(3)[(ax + 1) % 3] * 0.5; e2 = np.eye(3)[(ax + 2) % 3] * 0.5
         v = np.stack([g, g + e1, g + e1 + e2], 1)
-    else:              # coincident copies
+    elif kind == 3:    # coincident copies
         m = max(n // 4, 8)
         base = rng.uniform(-2, 2, (m, 1, 3)) + rng.normal(0, 0.3, (m, 3, 3))
         v = np.concatenate([base] * 4)[rng.permutation(4 * m)]
+    elif kind == 4:    # two or three differently triangulated sheets in ONE plane: near ties between leaves everywhere (shortcut rewalks)
+        ax = int(rng.integers(0, 3)); h = float(rng.uniform(-1, 1)); vs = []
+        for _ in range(int(rng.integers(2, 4))):
+            nx, nz = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+            xs, zs = np.linspace(-2, 2, nx + 1), np.linspace(-2, 2, nz + 1)
+            X, Z = np.meshgrid(xs, zs, indexing="ij")
+            def P(i, j):
+                q = np.zeros(X[:-1, :-1].shape + (3,)); q[..., ax] = h; q[..., (ax + 1) % 3] = X[i, j]; q[..., (ax + 2) % 3] = Z[i, j]
+                return q.reshape(-1, 3)
+            a, b, c, d_ = P(np.s_[:-1], np.s_[:-1]), P(np.s_[1:], np.s_[:-1]), P(np.s_[1:], np.s_[1:]), P(np.s_[:-1], np.s_[1:])
+            vs += [np.stack([a, b, c], 1), np.stack([a, c, d_], 1)]
+        v = np.concatenate(vs)
+    else:              # mirror-image pairs in the plane x = y sharing the edge that lies in it: EXACT ties between leaves for rays in that plane
+        m = max(n // 2, 8)
+        pq = rng.uniform(-2, 2, (m, 2, 2)); r = rng.uniform(-2, 2, (m, 3)); r[:, 1] = r[:, 0] + rng.choice([-1, 1], m) * rng.uniform(0.3, 1.0, m)
+        Pm, Qm = np.stack([pq[:, 0, 0], pq[:, 0, 0], pq[:, 0, 1]], 1), np.stack([pq[:, 1, 0], pq[:, 1, 0], pq[:, 1, 1]], 1)
+        v = np.concatenate([np.stack([Pm, Qm, r], 1), np.stack([Pm, Qm, r[:, [1, 0, 2]]], 1)])
     v = v * scale
     n = len(v)
     t = np.zeros((n, 25), np.float32)
@@ -51,7 +68,17 @@ for it in range(n_scenes):
     toward = on_tri(k) - far; toward /= np.maximum(np.linalg.norm(toward, axis=1, keepdims=True), 1e-30)
     vert = vf[rng.integers(0, n, k), rng.integers(0, 3, k)]
     edge = vert + (vf[rng.integers(0, n, k), rng.integers(0, 3, k)] - vert) * 0.0    # (vertices again: shared corners)
+    # rays inside the plane x = y (kind 5: they meet the shared edges; elsewhere just more rays)
+    tgt = on_tri(k); tgt[:, 1] = tgt[:, 0]
+    o2 = rng.uniform(-4, 4, (k, 2)) * scale
+    org_p = np.stack([o2[:, 0], o2[:, 0], o2[:, 1]], 1).astype(np.float32)
+    d_p = tgt.astype(np.float32) - org_p; d_p[:, 1] = d_p[:, 0]
+    if kind == 5:      # aim at the shared edges themselves
+        w = rng.uniform(0.05, 0.95, (k, 1)); e = rng.integers(0, n // 2, k)
+        tgt = (vf[e, 0] * w + vf[e, 1] * (1 - w)).astype(np.float32); tgt[:, 1] = tgt[:, 0]
+        d_p = tgt - org_p; d_p[:, 1] = d_p[:, 0]
     rays = np.concatenate([
+        np.concatenate([org_p, d_p], 1),
         np.concatenate([on_tri(k) + 1e-5 * scale * dirs, dirs], 1),
         np.concatenate([on_tri(k), axis_dirs], 1),
         np.concatenate([vert, dirs * rng.uniform(0.1, 5.0, (k, 1))], 1),
