@@ -14,6 +14,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 gpu = rt.Renderer(0)
 bad = 0
 rewalks = short_rays = 0
+visits = {"shortcut": 0, "megakernel": 0}
 t0 = time.time()
 for it in range(n_scenes):
     seed = seed0 + it
@@ -36,11 +37,13 @@ for it in range(n_scenes):
         walk = [] if mode == "shortcut" else ["inner_visits", "leaf_visits", "tri_tests"]   # (the shortcut walk's own visits are not the reference's)
         cnt = all(getattr(st, f) == getattr(ost, f) for f in ["rays", "hits", "texel_fetches", "light_tests"] + walk)
         rewalks += st.shortcut_rewalks; short_rays += st.rays if mode == "shortcut" else 0
+        if mode in ("shortcut", "megakernel"): visits[mode] += st.dev_inner_visits
         if not (same and cnt):
             bad += 1
             print(f"MISMATCH seed {seed} mode {mode} lights {len(sc.lights())} tris {sc.n_tris} image {same} counters {cnt}", flush=True)
     if it % 10 == 9:
         print(f"{it + 1} scenes, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 gpu.close()
-print("render fuzz done:", n_scenes, "scenes,", bad, "mismatches;", rewalks, "shortcut rewalks in", short_rays, "rays")
+print("render fuzz done:", n_scenes, "scenes,", bad, "mismatches;", rewalks, "shortcut rewalks in", short_rays, "rays; inner items visited",
+      visits["shortcut"], "on the shortcut walk,", visits["megakernel"], "on the reference's")
 sys.exit(1 if bad else 0)
