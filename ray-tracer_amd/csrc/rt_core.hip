@@ -2355,7 +2355,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      in that order, see wave_light_pdf).
     const int nl = s->n_light_tris;
     const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
-    const size_t light_box_off = (size_t)std::max(nl, 1) * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records
+    const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
     const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
     std::vector<float>& lights = L.lights;
     lights.assign(light_place_off + (size_t)((std::max(nl, 1) + 3) & ~3), 0.f);
@@ -2411,11 +2411,12 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         const H3 cr = hcross(e1, e2);
         const H3 nrm = hnormalize(cr);
         const float area = 0.5f * hlen(cr);
-        float* Lr = &lights[(size_t)j * 20];
+        float Lr[20];
         Lr[0] = p1.x; Lr[1] = p1.y; Lr[2] = p1.z; Lr[3] = e1.x; Lr[4] = e1.y; Lr[5] = e1.z;
         Lr[6] = e2.x; Lr[7] = e2.y; Lr[8] = e2.z; Lr[9] = nrm.x; Lr[10] = nrm.y; Lr[11] = nrm.z;
         Lr[12] = area; Lr[13] = p2.x; Lr[14] = p2.y; Lr[15] = p2.z; Lr[16] = p3.x; Lr[17] = p3.y; Lr[18] = p3.z;
         Lr[19] = i2f(i);                                    // the light's place in the reference's list
+        for (int k = 0; k < 20; k++) lights[RT_LIGHT_F4(j, k / 4) * 4 + (size_t)(k % 4)] = Lr[k];  // plane by plane per group (rt_device.h)
         lights[light_place_off + (size_t)i] = i2f(j);
         float* B = &lights[light_box_off + (size_t)(j / RT_LIGHT_GROUP) * 8];
         for (int k = 0; k < 3; k++) {

@@ -64,7 +64,8 @@ namespace rtd {
 // leaf visit and all the leaf's triangle tests, like the walk it replaces.
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
-// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) reference index (int bits)
+// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) reference index (int bits); stored plane by plane
+//            per group of RT_LIGHT_GROUP lights (RT_LIGHT_F4 below)
 // light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [16 g, 16 g + 16), behind the light records
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
@@ -113,6 +114,14 @@ struct Params {
     int tiles_x, n_tiles;
 };
 
+// Light records are stored plane by plane per group of RT_LIGHT_GROUP lights: float4 p of light j stands at
+// ((j / G) * 5 + p) * G + j % G, so that the G lanes of a slot which test the G lights of a group (wave_light_pdf) read
+// 16 G contiguous bytes per request instead of 16 bytes every 80 (the texture path serves a request in proportion to
+// the lines it touches: it was the limit of the light loop).
+#ifndef RT_LIGHT_GROUP
+#define RT_LIGHT_GROUP 16  // (8 / 16 / 32 measured: profiles/r02_ab.txt)
+#endif
+#define RT_LIGHT_F4(j, p) ((((size_t)(j) / RT_LIGHT_GROUP) * 5 + (p)) * RT_LIGHT_GROUP + (size_t)(j) % RT_LIGHT_GROUP)
 #define RT_STACK_ENTRIES 24   // per-lane LDS stack depth (a depth-D tree needs D entries here)
 #define RT_WAVES_PER_BLOCK 4
 
@@ -981,8 +990,8 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             if (sc.n_lights > 0) {
                 if (u01(A.x) < 0.5f) {  // dims k0 (choice), k1 (raw pick), k2, k3
                     const uint32_t pick = A.y % (uint32_t)sc.n_lights;
-                    const float4* L = sc.lights + 5 * (size_t)sc.light_place[pick];
-                    const float4 l0 = L[0], l3 = L[3], l4 = L[4];
+                    const int pj = sc.light_place[pick];
+                    const float4 l0 = sc.lights[RT_LIGHT_F4(pj, 0)], l3 = sc.lights[RT_LIGHT_F4(pj, 3)], l4 = sc.lights[RT_LIGHT_F4(pj, 4)];
                     outgoing = itri_sample(hitPos, u01(A.z), u01(A.w), mk(l0.x, l0.y, l0.z), mk(l3.y, l3.z, l3.w), mk(l4.x, l4.y, l4.z));
                     sampledLight = true;
                 } else {
@@ -1010,8 +1019,9 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             }
             float pdf_light = 0.0f;
             for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323, in the reference's order
-                const float4* L = sc.lights + 5 * (size_t)sc.light_place[i];
-                const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+                const int pj = sc.light_place[i];
+                const float4 l0 = sc.lights[RT_LIGHT_F4(pj, 0)], l1 = sc.lights[RT_LIGHT_F4(pj, 1)], l2 = sc.lights[RT_LIGHT_F4(pj, 2)],
+                             l3 = sc.lights[RT_LIGHT_F4(pj, 3)];
                 if (STATS) { cn.lights++; cn.dev_lights++; }
                 pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x),
                                       mk(l2.y, l2.z, l2.w), l3.x) / (float)sc.n_lights;
@@ -1063,9 +1073,6 @@ __device__ __forceinline__ void finish_type5(const Scene& sc, PathState& ray, co
 // selection (wave_light_pdf_ordered).  Per pass over RT_LIGHT_CHUNK lights: every waiting lane marks the groups of
 // RT_LIGHT_GROUP lights whose bounds its ray can reach (all lanes at once, bounds through the scalar cache), then
 // lane after lane the wave tests the marked groups' triangles, four groups per step.
-#ifndef RT_LIGHT_GROUP
-#define RT_LIGHT_GROUP 16  // (8 / 16 / 32 measured: profiles/r02_ab.txt)
-#endif
 #define RT_LIGHT_CHUNK (64 * RT_LIGHT_GROUP)
 
 // Exact sum for ONE query (wave-uniform hp, og) whatever the number of nonzero terms: pass after pass over all the
@@ -1084,8 +1091,8 @@ __device__ __forceinline__ float wave_light_pdf_ordered(const Scene& sc, f3 hp, 
             int oi = 0x7fffffff;
             if (i < sc.n_lights) {
                 if (STATS) cn.dev_lights++;
-                const float4* L = sc.lights + 5 * (size_t)i;
-                const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3], l4 = L[4];
+                const float4 l0 = sc.lights[RT_LIGHT_F4(i, 0)], l1 = sc.lights[RT_LIGHT_F4(i, 1)], l2 = sc.lights[RT_LIGHT_F4(i, 2)],
+                             l3 = sc.lights[RT_LIGHT_F4(i, 3)], l4 = sc.lights[RT_LIGHT_F4(i, 4)];
                 term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w), l3.x) /
                        (float)sc.n_lights;
                 oi = __float_as_int(l4.w);
@@ -1145,8 +1152,9 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
                 float term = 0.0f;
                 if (gs >= 0 && i < sc.n_lights) {
                     if (STATS) cn.dev_lights++;
-                    const float4* L = sc.lights + 5 * (size_t)i;
-                    const float4 l0 = L[0], l1 = L[1], l2 = L[2], l3 = L[3];
+                    // (group gs, light sub: plane p of the group is 16 RT_LIGHT_GROUP contiguous bytes)
+                    const float4* L = sc.lights + ((size_t)(base / RT_LIGHT_GROUP + gs) * 5) * RT_LIGHT_GROUP + sub;
+                    const float4 l0 = L[0], l1 = L[RT_LIGHT_GROUP], l2 = L[2 * RT_LIGHT_GROUP], l3 = L[3 * RT_LIGHT_GROUP];
                     term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
                                     l3.x) / (float)sc.n_lights;
                 }
