@@ -74,6 +74,7 @@ struct Scene {
     const float4* ref_boxes; // the reference's node boxes as uploaded, (min, 0) (max, 0) per node: the shortcut certificate tests the hit's leaf
     int short_root;          // item of the shortcut tree's root, RT_TRAV_DONE without one
     int short_base;          // first item of the window [short_base, short_base + n_cached) the shortcut walk caches in LDS
+    int short_runs;          // the shortcut tree stands over the runs of the item stream (short ones: two triangle tests per leaf iteration pay)
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
