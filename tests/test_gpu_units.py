@@ -524,6 +524,25 @@ def test_full_hd_properties(rt, gpu, scenes):
     assert np.array_equal(out, a)                                           # 8-way tile-row gather == 1 GPU
 
 
+@pytest.mark.parametrize("name,spp", [("scene.txt", 64), ("scene2.txt", 16), ("scene2_is.txt", 8)])
+def test_shortcut_walk_at_full_hd(rt, gpu, scenes, name, spp):
+    """BASELINE configs 2 and 3 at 1920x1080 (config 2 with all its 64 spp): the default walk (shortcut tree first) gives the
+    frame of the reference's walk bit for bit, in fewer node visits; a few searches in a hundred million are not certified
+    and walk the reference's tree after all."""
+    sc = scenes(name)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=spp, width=1920, height=1080, flags=rt.F_DEFAULT | rt.F_STATS)
+    gpu.reset(); ref = gpu.render(p); a = gpu.readback()
+    q = rt.RenderParams.from_buffer_copy(p); q.flags |= rt.F_SHORTCUT_STATS
+    gpu.reset(); st = gpu.render(q)
+    assert np.array_equal(gpu.readback(), a)
+    assert (st.paths, st.rays, st.hits, st.texel_fetches, st.light_tests) == (ref.paths, ref.rays, ref.hits, ref.texel_fetches, ref.light_tests)
+    assert st.dev_inner_visits < 0.6 * ref.dev_inner_visits and 0 < st.shortcut_rewalks < 1e-5 * st.rays and ref.shortcut_rewalks == 0
+    q.flags = rt.F_DEFAULT
+    gpu.reset(); gpu.render(q)
+    assert np.array_equal(gpu.readback(), a)
+
+
 def test_config4_field_at_full_size(ob, rt, gpu):
     """BASELINE config 4 at its real size: 628 dragons = 9 999 018 triangles in the reference's depth-16 tree (leaves of
     ~150 triangles, each with a sub-tree of its own on the device), 3840x2160.  Size-independent properties: the path
@@ -547,11 +566,24 @@ def test_config4_field_at_full_size(ob, rt, gpu):
         gpu.reset(); gpu.render(b)
         out[[y for y in range(H) if (y // 16) % 8 == r]] = gpu.readback()
     assert np.array_equal(out, img)
+    # the default walk: the shortcut tree (over the 65 k reference leaves here) first -- the same frame bit for bit, in
+    # about half the node visits, and a handful of searches that had to walk the reference's tree after all
+    s = rt.RenderParams.from_buffer_copy(p); s.flags |= rt.F_SHORTCUT_STATS
+    gpu.reset(); st_s = gpu.render(s)
+    assert np.array_equal(gpu.readback(), img)
+    assert (st_s.rays, st_s.hits, st_s.texel_fetches) == (st.rays, st.hits, st.texel_fetches)
+    assert st_s.dev_inner_visits < 0.7 * st.dev_inner_visits and st_s.shortcut_rewalks < 1e-5 * st_s.rays
+    s.flags = rt.F_DEFAULT
+    gpu.reset(); gpu.render(s)
+    assert np.array_equal(gpu.readback(), img)
     # the oracle on the same 10M triangles at a sixth of the resolution (its plain walk tests ~600 triangles per ray)
     c = rt.default_params(sc.camera, spp=2, width=640, height=360, flags=rt.F_DEFAULT | rt.F_STATS | rt.F_MEGAKERNEL)
     gpu.reset(); st_c = gpu.render(c); crop = gpu.readback()
     o, ost = ob.render(sc, c, n_threads=16)
     assert np.array_equal(crop, o)
+    c.flags = rt.F_DEFAULT
+    gpu.reset(); gpu.render(c)
+    assert np.array_equal(gpu.readback(), o)                                # (shortcut walk against the oracle)
     assert (st_c.rays, st_c.inner_visits, st_c.leaf_visits, st_c.tri_tests, st_c.hits) == \
            (ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
 
