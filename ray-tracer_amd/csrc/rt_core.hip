@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                                                                               unsigned int n_paths, int n_mats_lds) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cache_base = FAST ? sc.short_base : 0;  // the LDS holds items [cache_base, cache_base + n_cached)
+    const int cache_base = (FAST && !TLDS) ? sc.short_base : 0;  // the LDS holds items [cache_base, cache_base + n_cached) (TLDS: all of them)
     for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[4 * (size_t)cache_base + i];
     int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
     // the material table behind the stacks (n_mats_lds = 0: too many materials, they stay in device memory)
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 RT_PROF_LANE(cn, 1);
                 trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
-                for (int k = 1; k < (FAST ? RT_INNER_STEPS_SHORT : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
+                for (int k = 1; k < ((FAST && !TLDS) ? RT_INNER_STEPS_SHORT : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
                     if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
             }
         }
@@ -1390,7 +1390,7 @@ struct HostLayout {
     std::vector<int> place;  // reference triangle id -> place in the item stream
     std::vector<float> ref_boxes;  // the reference's node boxes as uploaded, 8 floats per node (the shortcut tree's certificate reads the leaf's)
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
-    bool short_runs = false;
+    bool short_runs = false, short_single = false;
     int n_short = 0, short_root = RT_TRAV_DONE, short_base = 0, short_depth = 0;  // shortcut tree (rt_device.h): nodes, root item, first item of its LDS window, stack entries
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
@@ -1854,10 +1854,13 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(reference leaf node, or first place of a run)
     std::vector<ShortNode> shorts;
     int short_root = -1, short_levels = 0, below_leaf = 0;
-    bool short_runs = false;
+    bool short_runs = false, short_single = false;
     for (int wi = 0; wi < n_workers; wi++) below_leaf = std::max(below_leaf, work[(size_t)wi].max_below_leaf);
     {
-        bool want = nn > 1 && ntri >= sub_min_tris && !getenv("RT_NO_SHORTCUT");
+        // a scene too small for sub-trees (the Cornell box): the shortcut tree over its SINGLE triangles -- a shortcut search
+        // then leaves a leaf after one test, whatever the 'last' flags of the reference's leaves say (Scene::short_single)
+        const bool tiny = ntri < sub_min_tris || getenv("RT_SHORT_SINGLE");  // (RT_SHORT_SINGLE: experiments only)
+        bool want = nn > 1 && ntri >= 2 && !getenv("RT_NO_SHORTCUT") && !(tiny && getenv("RT_NO_SHORTCUT_TINY"));
         for (int i = 0; i < nn && want; i++) {
             const rt_bvh_node& n = s->nodes[i];
             if (n.child_a == -1) continue;
@@ -1880,13 +1883,16 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     if (n.child_a != -1 || n.tri_len == 0) continue;
                     const size_t first = (size_t)(n.tri_offs / RT_TRI_FLOATS), cnt = (size_t)(n.tri_len / RT_TRI_FLOATS);
                     l++;
-                    for (size_t k = 0; k < cnt; k++) r += tflags[first + k] & 1;
+                    if (tiny) r += cnt;
+                    else
+                        for (size_t k = 0; k < cnt; k++) r += tflags[first + k] & 1;
                 }
                 c_runs[(size_t)wi + 1] = r;
                 c_leaves[(size_t)wi + 1] = l;
             });
             for (int wi = 0; wi < nr; wi++) { c_runs[(size_t)wi + 1] += c_runs[(size_t)wi]; c_leaves[(size_t)wi + 1] += c_leaves[(size_t)wi]; }
-            short_runs = c_runs[(size_t)nr] <= runs_max && !getenv("RT_SHORT_LEAVES");
+            short_runs = tiny || (c_runs[(size_t)nr] <= runs_max && !getenv("RT_SHORT_LEAVES"));
+            short_single = tiny;
             const std::vector<size_t>& off = short_runs ? c_runs : c_leaves;
             prims.resize(off[(size_t)nr]);
             // boxes the sub-tree build has formed already (padded once; the shortcut builder pads again): a candidate leaf's
@@ -1909,13 +1915,13 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     const rt_bvh_node& n = s->nodes[i];
                     if (n.child_a != -1 || n.tri_len == 0) continue;
                     const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-                    const bool whole = !short_runs || sub_root[i] < 0;  // the leaf as one unit
+                    const bool whole = !short_single && (!short_runs || sub_root[i] < 0);  // the leaf as one unit
                     for (int k = 0; k < cnt;) {
-                        int len = cnt - k;
-                        if (!whole)
+                        int len = short_single ? 1 : cnt - k;
+                        if (!whole && !short_single)
                             for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
                         ShortPrim& p = prims[o++];
-                        const float* known = whole ? leaf_box[i] : (run_src[(size_t)first + k] >= 0 ? subs[(size_t)(run_src[(size_t)first + k] >> 1)].box[run_src[(size_t)first + k] & 1] : nullptr);
+                        const float* known = short_single ? nullptr : whole ? leaf_box[i] : (run_src[(size_t)first + k] >= 0 ? subs[(size_t)(run_src[(size_t)first + k] >> 1)].box[run_src[(size_t)first + k] & 1] : nullptr);
                         if (known) {
                             memcpy(p.b, known, sizeof(p.b));
                         } else {
@@ -2455,6 +2461,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.short_root = short_root >= 0 ? short_index[(size_t)short_root] : RT_TRAV_DONE;
     L.short_base = short_base;
     L.short_runs = short_runs;
+    L.short_single = short_single;
     L.short_depth = n_short > 0 ? short_levels + below_leaf : 0;
     L.light_box_off = light_box_off;
     L.light_place_off = light_place_off;
@@ -2491,6 +2498,7 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     sc.short_root = L.short_root;
     sc.short_base = L.short_base;
     sc.short_runs = L.short_runs ? 1 : 0;
+    sc.short_single = L.short_single ? 1 : 0;
     sc.n_inner = L.n_inner;
     sc.n_sub = L.n_sub;
     sc.cull_far = RT_CULL_FAR * L.scene_scale;
@@ -2555,6 +2563,7 @@ int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items,
         info->short_root = h->L.short_root;
         info->short_base = h->L.short_base;
         info->short_depth = h->L.short_depth;
+        info->short_single = h->L.short_single ? 1 : 0;
     }
     if (items) *items = h->L.items.data();
     if (places) *places = h->L.place.data();
@@ -2653,7 +2662,7 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     // a scene whose whole item stream fits (the Cornell box): the triangles too, so that a leaf step reads the LDS
     // instead of L1 (path-parallel kernel only: its leaf step knows)
     const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris;
-    if (with_mats && !fast && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
+    if (with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
     t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
     t.grid = c->num_cus;
     return t;
@@ -2678,6 +2687,10 @@ paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop, bool 
     // the shortcut walk: plain triangle scenes with sub-tree style nodes (its own), no extras
     static const paths_fn shortcut[4] = {rt_render_paths_kernel<false, true, false, false, false, true>, rt_render_paths_kernel<true, true, false, false, false, true>,
                                          rt_render_paths_kernel<false, true, false, true, false, true>,  rt_render_paths_kernel<true, true, false, true, false, true>};
+    // ... of a scene whose whole item stream sits in the LDS
+    static const paths_fn shortcut_tiny[4] = {rt_render_paths_kernel<false, true, false, false, true, true>, rt_render_paths_kernel<true, true, false, false, true, true>,
+                                              rt_render_paths_kernel<false, true, false, true, true, true>,  rt_render_paths_kernel<true, true, false, true, true, true>};
+    if (fast && tlds) return shortcut_tiny[(stats ? 1 : 0) | (coop ? 2 : 0)];
     if (fast) return shortcut[(stats ? 1 : 0) | (coop ? 2 : 0)];
 #define RT_V4(C) \
     rt_render_paths_kernel<false, false, false, C>, rt_render_paths_kernel<true, false, false, C>, \
@@ -2745,8 +2758,8 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
     for (int v = 0; v < 32; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0, (v & 8) != 0, (v & 16) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
-    for (int v = 0; v < 4; v++)
-        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, true, false, (v & 2) != 0, false, true),
+    for (int v = 0; v < 8; v++)
+        HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, true, false, (v & 2) != 0, (v & 4) != 0, true),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     for (int v = 0; v < 8; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)pool_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
@@ -2807,7 +2820,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
         S = (S + 1) / 2;
     }
     const paths_fn kfn = paths_kernel_variant(want_stats, c->sc.n_sub > 0, (P.flags & (RT_F_VOLUME | RT_F_RAYMARCH)) != 0,
-                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN, !fast && tc.n_cached > c->sc.n_inner, fast);
+                                            c->sc.n_lights >= RT_LIGHTS_COOP_MIN, tc.n_cached > c->sc.n_inner, fast);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kfn, 64 * RT_MEGA_WAVES, tc.lds_bytes) != hipSuccess || occ < 1) occ = 1;
     const PoolCfg pc = pool ? pool_cfg(c) : PoolCfg();

@@ -74,6 +74,7 @@ struct Scene {
     const float4* ref_boxes; // the reference's node boxes as uploaded, (min, 0) (max, 0) per node: the shortcut certificate tests the hit's leaf
     int short_root;          // item of the shortcut tree's root, RT_TRAV_DONE without one
     int short_base;          // first item of the window [short_base, short_base + n_cached) the shortcut walk caches in LDS
+    int short_single;        // ... over single triangles (tiny scenes): a shortcut search leaves a leaf after ONE test, whatever its 'last' flag
     int short_runs;          // the shortcut tree stands over the runs of the item stream (short ones: two triangle tests per leaf iteration pay)
     const float4* tri_cold;
     const float4* mats;
@@ -591,7 +592,7 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
             t.rival = fminf(t.rival, nd);
         }
     }
-    if (flags & 1) trav_pop(t, stk);
+    if ((flags & 1) || (FAST && sc.short_single && t.rival >= 0.0f)) trav_pop(t, stk);
     else t.cur++;
 }
 
@@ -649,7 +650,7 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
     if (TLDS) {
         float4 q0, q1, q2, q3;
         load_cached_item(t.cur, n_cached, q0, q1, q2, q3);  // (the fourth piece is padding: its read is dropped)
-        visit_triangle<STATS, SUB>(sc, t, stk, cn, t.cur, q0, q1, q2);
+        visit_triangle<STATS, SUB, FAST>(sc, t, stk, cn, t.cur, q0, q1, q2);
         return;
     }
     const float4* w = sc.items + 4 * (size_t)t.cur;

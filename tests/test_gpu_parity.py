@@ -272,7 +272,7 @@ def test_image_matches_oracle_same_rng(ob, rt, gpu, scenes, name, size, spp, bou
         assert getattr(st, f) == getattr(ost, f), f
 
 
-@pytest.mark.parametrize("name,size,spp", [("scene.txt", 128, 16), ("scene2.txt", 96, 8), ("scene2_is.txt", 64, 4)])
+@pytest.mark.parametrize("name,size,spp", [("scene.txt", 128, 16), ("scene2.txt", 96, 8), ("scene2_is.txt", 64, 4), ("scene_cornellbox.txt", 256, 16)])
 def test_shortcut_tree_gives_the_oracles_image(ob, rt, gpu, scenes, name, size, spp):
     """The fused kernel's default walk: the shortcut tree first, the reference's tree for the rays whose result is not
     certified (rt_device.h).  Raw sums as the oracle's bit for bit, with and without counters; every counter that does
@@ -293,7 +293,10 @@ def test_shortcut_tree_gives_the_oracles_image(ob, rt, gpu, scenes, name, size, 
     assert np.array_equal(gpu.readback(), o) and ref.inner_visits == ost.inner_visits and ref.shortcut_rewalks == 0
     print(f"{name}: inner items per ray {st.dev_inner_visits / st.rays:.1f} (reference's walk {ref.dev_inner_visits / ref.rays:.1f}), "
           f"triangle tests {st.dev_tri_tests / st.rays:.2f} ({ref.dev_tri_tests / ref.rays:.2f}), rewalks {st.shortcut_rewalks} of {st.rays} rays")
-    assert st.dev_inner_visits < 0.8 * ref.dev_inner_visits
+    if name == "scene_cornellbox.txt":    # 36 triangles: the shortcut tree stands over single triangles (more node visits, a third of the triangle tests)
+        assert st.dev_tri_tests < 0.5 * ref.dev_tri_tests and st.dev_inner_visits + st.dev_tri_tests < ref.dev_inner_visits + ref.dev_tri_tests
+    else:
+        assert st.dev_inner_visits < 0.8 * ref.dev_inner_visits
     assert st.shortcut_rewalks < 0.02 * st.rays
     q.flags = p.flags | rt.F_REFWALK
     gpu.reset(); gpu.render(q)

@@ -60,16 +60,19 @@ def test_presorted_sweep_builds_the_same_sub_trees(rt, monkeypatch, seed, n, dep
 
 
 @pytest.mark.parametrize("seed,n,depth,by_leaves", [(1, 900, 4, False), (2, 3000, 16, False), (3, 400, 1, False), (1, 900, 4, True),
-                                                   (2, 3000, 16, True)])
+                                                   (2, 3000, 16, True), (4, 200, 3, "single")])
 def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
-    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    single = by_leaves == "single"                                     # a scene too small for sub-trees: shortcut tree over single triangles
+    by_leaves = by_leaves is True
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "256" if single else "0")
     if by_leaves:                                                      # the shortcut tree over whole reference leaves (huge scenes)
         monkeypatch.setenv("RT_SHORT_LEAVES", "1")
     sc, _ = make_scene(rt, seed, n, depth)
     info, items, places = rt.device_layout(sc)
     boxes, entries, third, is_sub, flags, leaf_end, ids = unpack(items, info)
     nodes, tris = sc.nodes(), sc.tris()
-    assert info.n_tris == n and info.n_sub == is_sub.sum() > 0 and info.root_entry == 0
+    assert info.n_tris == n and info.n_sub == is_sub.sum() and (single or info.n_sub > 0) and info.root_entry == 0
+    assert bool(info.short_single) == single and (not single or info.n_short == n - 1)
     assert sorted(places.tolist()) == list(range(n)) and np.array_equal(ids[places], np.arange(n))
     v = tris[:, :9].reshape(n, 3, 3)
     placed = v[ids]                                                    # triangle geometry in item order
@@ -145,10 +148,10 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
 
     def walk_short(entry, d):
         nonlocal depth_seen
-        if entry >= info.n_inner and not by_leaves:                    # a run of triangles up to a 'last' flag
+        if entry >= info.n_inner and not by_leaves:                    # a run of triangles up to a 'last' flag (or ONE triangle)
             depth_seen = max(depth_seen, d)
-            run = leaf_run(entry - info.n_inner)
-            assert entry == info.n_inner or flags[entry - info.n_inner - 1] & 1
+            run = [entry - info.n_inner] if info.short_single else leaf_run(entry - info.n_inner)
+            assert info.short_single or entry == info.n_inner or flags[entry - info.n_inner - 1] & 1
             seen[run] += 1
             return run
         if entry in leaf_entries and by_leaves:
@@ -261,8 +264,8 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
                                         sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
                                     elif this_leaf != best_leaf:
                                         rival = np.fmin(rival, nd)
-                    if not (as_int(w[9:10])[0] & 1):
-                        cur += 1
+                    if not (as_int(w[9:10])[0] & 1) and not (fast and info.short_single):
+                        cur += 1                                           # (a shortcut search over single triangles pops after one test)
                         continue
                 if not stack:
                     break
@@ -294,14 +297,16 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
 
 
 @pytest.mark.parametrize("seed,n,depth,coincident,by_leaves", [(11, 700, 3, False, False), (12, 1500, 16, False, False), (13, 150, 2, True, False),
-                                                               (11, 700, 3, False, True), (13, 150, 2, True, True)])
+                                                               (11, 700, 3, False, True), (13, 150, 2, True, True),
+                                                               (14, 200, 3, False, "single"), (15, 40, 2, True, "single")])
 def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, seed, n, depth, coincident, by_leaves):
-    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
-    if by_leaves:
+    single = by_leaves == "single"                                                 # (tiny scene: shortcut tree over single triangles)
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "256" if single else "0")
+    if by_leaves is True:
         monkeypatch.setenv("RT_SHORT_LEAVES", "1")
     sc, rng = make_scene(rt, seed, n, depth, coincident)
     info, items, _ = rt.device_layout(sc)
-    assert info.n_sub > 0
+    assert (info.n_sub > 0) != single and bool(info.short_single) == single
     k = 250
     v = sc.tris()[:, :9].reshape(-1, 3, 3).astype(np.float64)
     target = np.einsum("kj,kjc->kc", rng.dirichlet([1, 1, 1], k), v[rng.integers(0, len(v), k)])
