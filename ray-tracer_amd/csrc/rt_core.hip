@@ -239,6 +239,15 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_INNER_STEPS_SHORT
 #define RT_INNER_STEPS_SHORT 3  // ... on the shortcut walk (fewer, less alike walks: 2 / 3 / 4 / 6: 23.5 / 23.0 / 23.4 / 23.45 ms; the Cornell box, which has none, loses 6 % with 3)
 #endif
+#ifndef RT_INNER_ROLLED
+#define RT_INNER_ROLLED 0
+#endif
+#ifndef RT_INNER_STEPS_TINY
+#define RT_INNER_STEPS_TINY 6   // ... on the shortcut walk of a scene that sits in the LDS entirely (the Cornell box, 256 spp: 4 / 5 / 6 / 7 / 8 / 12 = 109.1 / 109.0 / 97.3 / 98.4 / 98.8 / 99.8 ms at a vertex vote of 48)
+#endif
+#ifndef RT_REGEN_MIN_TINY
+#define RT_REGEN_MIN_TINY 48    // vertex-pass vote there (40 / 44 / 48 / 52 / 56: 100.5 / 97.6 / 97.3 / 97.7 / 101.1 ms)
+#endif
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
                        // more bytes at the HBM: 3.18 vs 2.93 GB per frame of scene.txt; profiles/r02_ab.txt)
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     for (;;) {
         const unsigned long long mNeed = __ballot((unsigned)(t.cur + 2) < 2u);  // RT_TRAV_DONE or RT_LANE_NEW
         const unsigned long long mTrav = __ballot(t.cur >= 0);
-        if (__popcll(mNeed) >= RT_REGEN_MIN || mTrav == 0) {
+        if (__popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : RT_REGEN_MIN) || mTrav == 0) {
             if (mNeed == 0) break;  // every lane idle: no paths left
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
@@ -523,10 +532,16 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (at_inner) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
+#if RT_INNER_ROLLED  // (experiments: ONE copy of the visit's code in a counted loop)
+#pragma unroll 1
+                for (int k = 0; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)
+                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+#else
                 trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
-                for (int k = 1; k < ((FAST && !TLDS) ? RT_INNER_STEPS_SHORT : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
+                for (int k = 1; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
                     if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+#endif
             }
         }
 #else
