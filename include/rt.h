@@ -321,6 +321,7 @@ typedef struct rt_layout_info {
     int32_t short_base;  /* first item of the window the shortcut walk caches in LDS */
     int32_t short_depth; /* traversal stack entries of the shortcut walk */
     int32_t short_single; /* the shortcut tree stands over single triangles (scenes too small for sub-trees) */
+    int32_t short_cut;    /* huge scenes: levels below the reference's leaves at which the shortcut tree's leaves stand */
 } rt_layout_info;
 int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
 int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places);

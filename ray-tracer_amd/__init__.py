@@ -366,7 +366,7 @@ def band_rows_of(params: RenderParams) -> int:
 class LayoutInfo(C.Structure):  # rt_layout_info, include/rt.h
     _fields_ = [("n_inner", C.c_int32), ("n_sub", C.c_int32), ("n_tris", C.c_int32), ("root_entry", C.c_int32),
                 ("depth", C.c_int32), ("box_pad", C.c_float), ("cull_far", C.c_float), ("n_short", C.c_int32),
-                ("short_root", C.c_int32), ("short_base", C.c_int32), ("short_depth", C.c_int32), ("short_single", C.c_int32)]
+                ("short_root", C.c_int32), ("short_base", C.c_int32), ("short_depth", C.c_int32), ("short_single", C.c_int32), ("short_cut", C.c_int32)]
 
 
 def device_layout(scene: "Scene"):

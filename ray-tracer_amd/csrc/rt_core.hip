@@ -18,6 +18,7 @@
 //  * raw-sum accumulators + separate resolve kernels (needed for RCCL sum-reduce and progressive batches).
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -229,6 +230,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_REF_FRONT 1024        // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
+#define RT_SHORT_FRONT_MAX (1 << 18)  // ... with at most this many entries (the 10M-triangle field, 4 spp frames: leaves 15.56 ms, 2 levels below them --
+                                      // 262 k entries, 25 ms of build -- 14.43, 4 levels -- 1 M, 96 ms -- 14.43, 6 levels 14.49, runs -- 6.2 M, 0.5 s -- 13.8 to 14.5)
+#define RT_SHORT_CUT_MAX 6       // ... and then over what stands at most this many levels below the reference's leaves
 #define RT_SHORT_RUNS_MAX (1 << 20)  // shortcut tree over the runs of the item stream up to this many, over the reference's leaves above
 #define RT_SHORT_SWEEP_MAX 2048  // shortcut tree: full surface-area sweep up to this many leaves per node (64 in trees over more than 2^18: build time), 32 bins above
 #define RT_SUB_LEAF_MAX 8       // sub-leaves of more triangles than this are always split,
@@ -1406,6 +1410,7 @@ struct HostLayout {
     std::vector<float> ref_boxes;  // the reference's node boxes as uploaded, 8 floats per node (the shortcut tree's certificate reads the leaf's)
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
     bool short_runs = false, short_single = false;
+    int short_cut = 0;
     int n_short = 0, short_root = RT_TRAV_DONE, short_base = 0, short_depth = 0;  // shortcut tree (rt_device.h): nodes, root item, first item of its LDS window, stack entries
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
@@ -1866,10 +1871,11 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      the reference's own walk must return the same triangle, and the ray walks the reference's tree if not.
     //      Needs the reference's boxes to be nested (child inside parent), as its builder makes them.
     struct ShortPrim { float b[6]; float c[3]; float cost; int node; };
-    struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(reference leaf node, or first place of a run)
+    struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(ShortPrim::node of what hangs there)
     std::vector<ShortNode> shorts;
     int short_root = -1, short_levels = 0, below_leaf = 0;
     bool short_runs = false, short_single = false;
+    int short_cut = 0;  // levels below the reference's leaves at which the shortcut tree's own leaves stand (when it is not over runs)
     for (int wi = 0; wi < n_workers; wi++) below_leaf = std::max(below_leaf, work[(size_t)wi].max_below_leaf);
     {
         // a scene too small for sub-trees (the Cornell box): the shortcut tree over its SINGLE triangles -- a shortcut search
@@ -1908,49 +1914,113 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             for (int wi = 0; wi < nr; wi++) { c_runs[(size_t)wi + 1] += c_runs[(size_t)wi]; c_leaves[(size_t)wi + 1] += c_leaves[(size_t)wi]; }
             short_runs = tiny || (c_runs[(size_t)nr] <= runs_max && !getenv("RT_SHORT_LEAVES"));
             short_single = tiny;
-            const std::vector<size_t>& off = short_runs ? c_runs : c_leaves;
-            prims.resize(off[(size_t)nr]);
             // boxes the sub-tree build has formed already (padded once; the shortcut builder pads again): a candidate leaf's
             // and, through the sub-tree nodes, every sub-leaf's -- the triangles are not read again
             std::vector<const float*> leaf_box((size_t)nn, nullptr);
             for (const SubWork& w : work)
                 for (size_t k = 0; k < w.boxed.size(); k++) leaf_box[(size_t)w.boxed[k]] = &w.boxes[6 * k];
-            std::vector<int> run_src;  // place of a sub-leaf's first triangle -> 2 * sub node + side
-            if (short_runs && n_sub > 0) {
-                run_src.assign((size_t)ntri, -1);
-                par_ranges((size_t)n_sub, [&](int, size_t lo, size_t hi) {
-                    for (size_t j = lo; j < hi; j++)
-                        for (int k = 0; k < 2; k++)
-                            if (subs[j].e[k] < 0) run_src[(size_t)~subs[j].e[k]] = (int)(2 * j) + k;
-                });
-            }
-            par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {
-                size_t o = off[(size_t)wi];
-                for (size_t i = lo; i < hi; i++) {
-                    const rt_bvh_node& n = s->nodes[i];
-                    if (n.child_a != -1 || n.tri_len == 0) continue;
-                    const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-                    const bool whole = !short_single && (!short_runs || sub_root[i] < 0);  // the leaf as one unit
-                    for (int k = 0; k < cnt;) {
-                        int len = short_single ? 1 : cnt - k;
-                        if (!whole && !short_single)
-                            for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
-                        ShortPrim& p = prims[o++];
-                        const float* known = short_single ? nullptr : whole ? leaf_box[i] : (run_src[(size_t)first + k] >= 0 ? subs[(size_t)(run_src[(size_t)first + k] >> 1)].box[run_src[(size_t)first + k] & 1] : nullptr);
-                        if (known) {
-                            memcpy(p.b, known, sizeof(p.b));
-                        } else {
-                            memcpy(p.b, kEmpty, sizeof(p.b));
-                            for (int j = 0; j < len; j++) grow(p.b, at[(size_t)first + k + j]);
-                        }
-                        for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (p.b[c] + p.b[3 + c]);
-                        p.cost = short_runs ? (float)len : 1.0f + (float)std::min(len, 4);  // steps a ray spends below the box, roughly
-                        p.node = short_runs ? first + k : (int)i;  // the run's first place, or the leaf's node
-                        k += len;
-                    }
+            auto set_prim = [&](ShortPrim& p, const float* known, int first_place, int len, int code, float cost) {
+                if (known) {
+                    memcpy(p.b, known, sizeof(p.b));
+                } else {
+                    memcpy(p.b, kEmpty, sizeof(p.b));
+                    for (int j = 0; j < len; j++) grow(p.b, at[(size_t)first_place + j]);
                 }
-            });
-            if (short_runs) below_leaf = 0;
+                for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (p.b[c] + p.b[3 + c]);
+                p.cost = cost;   // steps a ray spends below the box, roughly
+                p.node = code;   // what hangs there: 2 * (first place of a run of triangles), or 2 * (sub-tree node) + 1
+            };
+            if (short_runs) {
+                prims.resize(c_runs[(size_t)nr]);
+                std::vector<int> run_src;  // place of a sub-leaf's first triangle -> 2 * sub node + side
+                if (n_sub > 0) {
+                    run_src.assign((size_t)ntri, -1);
+                    par_ranges((size_t)n_sub, [&](int, size_t lo, size_t hi) {
+                        for (size_t j = lo; j < hi; j++)
+                            for (int k = 0; k < 2; k++)
+                                if (subs[j].e[k] < 0) run_src[(size_t)~subs[j].e[k]] = (int)(2 * j) + k;
+                    });
+                }
+                par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {
+                    size_t o = c_runs[(size_t)wi];
+                    for (size_t i = lo; i < hi; i++) {
+                        const rt_bvh_node& n = s->nodes[i];
+                        if (n.child_a != -1 || n.tri_len == 0) continue;
+                        const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
+                        const bool whole = !short_single && sub_root[i] < 0;  // the leaf as one unit
+                        for (int k = 0; k < cnt;) {
+                            int len = short_single ? 1 : cnt - k;
+                            if (!whole && !short_single)
+                                for (len = 1; !(tflags[(size_t)first + k + len - 1] & 1); len++) {}
+                            const int src = (short_single || whole || run_src.empty()) ? -1 : run_src[(size_t)first + k];
+                            set_prim(prims[o++], short_single ? nullptr : whole ? leaf_box[i] : (src >= 0 ? subs[(size_t)(src >> 1)].box[src & 1] : nullptr),
+                                     first + k, len, 2 * (first + k), (float)len);
+                            k += len;
+                        }
+                    }
+                });
+                below_leaf = 0;
+            } else {
+                // Too many runs for the build: the shortcut tree stands over a FRONTIER of the leaves' sub-trees instead -- what
+                // is found `cut` levels below each reference leaf (sub-tree nodes there, runs met on the way); cut = 0 is the
+                // leaves themselves.  The deepest cut whose frontier has at most RT_SHORT_FRONT_MAX entries is taken.
+                const int D = RT_SHORT_CUT_MAX;
+                typedef std::array<size_t, RT_SHORT_CUT_MAX + 1> Counts;
+                auto count_below = [&](auto&& self, int entry, int k, Counts& c) -> void {
+                    if (entry < 0) {
+                        for (int d = k; d <= D; d++) c[(size_t)d]++;
+                        return;
+                    }
+                    c[(size_t)k]++;
+                    if (k < D) {
+                        self(self, subs[(size_t)entry].e[0], k + 1, c);
+                        self(self, subs[(size_t)entry].e[1], k + 1, c);
+                    }
+                };
+                std::vector<Counts> c_front((size_t)n_workers_max + 1);
+                for (auto& c : c_front) c.fill(0);
+                par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {
+                    Counts c;
+                    c.fill(0);
+                    for (size_t i = lo; i < hi; i++) {
+                        const rt_bvh_node& n = s->nodes[i];
+                        if (n.child_a != -1 || n.tri_len == 0) continue;
+                        count_below(count_below, sub_root[i] >= 0 ? sub_root[i] : -1, 0, c);
+                    }
+                    c_front[(size_t)wi + 1] = c;
+                });
+                for (int wi = 0; wi < nr; wi++)
+                    for (int d = 0; d <= D; d++) c_front[(size_t)wi + 1][(size_t)d] += c_front[(size_t)wi][(size_t)d];
+                int cut = 0;
+                for (int d = 1; d <= D; d++)
+                    if (c_front[(size_t)nr][(size_t)d] <= (size_t)RT_SHORT_FRONT_MAX) cut = d;
+                if (const char* e = getenv("RT_SHORT_CUT")) cut = std::min(D, std::max(0, atoi(e)));  // tests, experiments
+                prims.resize(c_front[(size_t)nr][(size_t)cut]);
+                par_ranges((size_t)nn, [&](int wi, size_t lo, size_t hi) {
+                    size_t o = c_front[(size_t)wi][(size_t)cut];
+                    auto emit = [&](auto&& self, int entry, int k, const float* box, int first, int cnt) -> void {
+                        if (entry < 0 && k == 0) {  // a leaf without a sub-tree: its triangles as one run
+                            set_prim(prims[o++], box, first, cnt, 2 * first, 1.0f + (float)std::min(cnt, 4));
+                        } else if (entry < 0) {     // a sub-leaf met above the cut
+                            int len = 1;
+                            while (!(tflags[(size_t)~entry + (size_t)len - 1] & 1)) len++;
+                            set_prim(prims[o++], box, ~entry, len, 2 * ~entry, (float)len);
+                        } else if (k == cut) {      // a sub-tree node on the cut: the walk goes on below it
+                            set_prim(prims[o++], box, 0, 0, 2 * entry + 1, k == 0 ? 1.0f + (float)std::min(cnt, 4) : 3.0f);
+                        } else {
+                            self(self, subs[(size_t)entry].e[0], k + 1, subs[(size_t)entry].box[0], first, cnt);
+                            self(self, subs[(size_t)entry].e[1], k + 1, subs[(size_t)entry].box[1], first, cnt);
+                        }
+                    };
+                    for (size_t i = lo; i < hi; i++) {
+                        const rt_bvh_node& n = s->nodes[i];
+                        if (n.child_a != -1 || n.tri_len == 0) continue;
+                        emit(emit, sub_root[i] >= 0 ? sub_root[i] : -1, 0, leaf_box[i], n.tri_offs / RT_TRI_FLOATS, n.tri_len / RT_TRI_FLOATS);
+                    }
+                });
+                below_leaf = std::max(0, below_leaf - cut);
+                short_cut = cut;
+            }
         }
         timer.stage("shortcut tree: leaves / runs and their boxes");
         const int np = (int)prims.size();
@@ -2342,7 +2412,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             w[0] = A[0]; w[1] = A[1]; w[2] = A[3]; w[3] = A[4];
             w[4] = B[0]; w[5] = B[1]; w[6] = B[3]; w[7] = B[4];
             w[8] = A[2]; w[9] = A[5]; w[10] = B[2]; w[11] = B[5];
-            for (int k = 0; k < 2; k++) w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : (short_runs ? n_inner + ~nd.e[k] : entry_of(~nd.e[k])));
+            for (int k = 0; k < 2; k++)  // (what hangs below: see ShortPrim::node)
+                w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : ((~nd.e[k] & 1) ? sub_index[(size_t)(~nd.e[k] >> 1)] : n_inner + (~nd.e[k] >> 1)));
             w[14] = i2f(0);
             w[15] = i2f(2);
         }
@@ -2477,6 +2548,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.short_base = short_base;
     L.short_runs = short_runs;
     L.short_single = short_single;
+    L.short_cut = short_cut;
     L.short_depth = n_short > 0 ? short_levels + below_leaf : 0;
     L.light_box_off = light_box_off;
     L.light_place_off = light_place_off;
@@ -2579,6 +2651,7 @@ int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items,
         info->short_base = h->L.short_base;
         info->short_depth = h->L.short_depth;
         info->short_single = h->L.short_single ? 1 : 0;
+        info->short_cut = h->L.short_cut;
     }
     if (items) *items = h->L.items.data();
     if (places) *places = h->L.place.data();

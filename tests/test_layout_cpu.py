@@ -60,13 +60,15 @@ def test_presorted_sweep_builds_the_same_sub_trees(rt, monkeypatch, seed, n, dep
 
 
 @pytest.mark.parametrize("seed,n,depth,by_leaves", [(1, 900, 4, False), (2, 3000, 16, False), (3, 400, 1, False), (1, 900, 4, True),
-                                                   (2, 3000, 16, True), (4, 200, 3, "single")])
+                                                   (2, 3000, 16, True), (4, 200, 3, "single"), (1, 900, 4, "cut2"), (3, 400, 1, "cut3")])
 def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     single = by_leaves == "single"                                     # a scene too small for sub-trees: shortcut tree over single triangles
-    by_leaves = by_leaves is True
+    cut = int(by_leaves[3:]) if isinstance(by_leaves, str) and by_leaves.startswith("cut") else 0
+    by_leaves = by_leaves is True or cut > 0
     monkeypatch.setenv("RT_SUB_MIN_TRIS", "256" if single else "0")
-    if by_leaves:                                                      # the shortcut tree over whole reference leaves (huge scenes)
-        monkeypatch.setenv("RT_SHORT_LEAVES", "1")
+    if by_leaves:                                                      # the shortcut tree over whole reference leaves (huge scenes),
+        monkeypatch.setenv("RT_SHORT_LEAVES", "1")                     # or over what stands `cut` levels below them in their sub-trees
+        monkeypatch.setenv("RT_SHORT_CUT", str(cut))
     sc, _ = make_scene(rt, seed, n, depth)
     info, items, places = rt.device_layout(sc)
     boxes, entries, third, is_sub, flags, leaf_end, ids = unpack(items, info)
@@ -154,9 +156,12 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
             assert info.short_single or entry == info.n_inner or flags[entry - info.n_inner - 1] & 1
             seen[run] += 1
             return run
-        if entry in leaf_entries and by_leaves:
-            reached.append(entry)
-            return walk(entry, d, False)
+        if by_leaves and (entry >= info.n_inner or kind[entry] == 1):  # a leaf, or a node / sub-leaf of its sub-tree on the cut
+            if entry in leaf_entries:
+                reached.append(entry)
+            if entry >= info.n_inner:
+                return walk(entry, d, bool(flags[entry - info.n_inner] & 4))
+            return walk(entry, d, third[entry] == 0)
         assert entry < info.n_inner and kind[entry] == 2
         below = []
         for side in range(2):
@@ -168,7 +173,8 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
         return below
 
     walk_short(info.short_root, 0)
-    assert (seen == 1).all() and (not by_leaves or sorted(reached) == sorted(leaf_entries))
+    assert (seen == 1).all() and (not by_leaves or cut > 0 or sorted(reached) == sorted(leaf_entries))
+    assert info.short_cut == cut and (cut == 0 or len(reached) < len(leaf_entries))
     assert depth_seen <= info.short_depth <= 32
     leaf_of = as_int(items[info.n_inner:, 12])                        # every triangle names its reference leaf
     for nd_i, nd in enumerate(nodes):
@@ -298,12 +304,14 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
 
 @pytest.mark.parametrize("seed,n,depth,coincident,by_leaves", [(11, 700, 3, False, False), (12, 1500, 16, False, False), (13, 150, 2, True, False),
                                                                (11, 700, 3, False, True), (13, 150, 2, True, True),
-                                                               (14, 200, 3, False, "single"), (15, 40, 2, True, "single")])
+                                                               (14, 200, 3, False, "single"), (15, 40, 2, True, "single"),
+                                                               (11, 700, 3, False, "cut2")])
 def test_float32_walk_of_the_item_stream_equals_the_oracle(ob, rt, monkeypatch, seed, n, depth, coincident, by_leaves):
     single = by_leaves == "single"                                                 # (tiny scene: shortcut tree over single triangles)
     monkeypatch.setenv("RT_SUB_MIN_TRIS", "256" if single else "0")
-    if by_leaves is True:
+    if by_leaves is True or by_leaves == "cut2":
         monkeypatch.setenv("RT_SHORT_LEAVES", "1")
+        monkeypatch.setenv("RT_SHORT_CUT", "2" if by_leaves == "cut2" else "0")
     sc, rng = make_scene(rt, seed, n, depth, coincident)
     info, items, _ = rt.device_layout(sc)
     assert (info.n_sub > 0) != single and bool(info.short_single) == single
