@@ -4,7 +4,7 @@
 // everything is a command-line option.
 //
 //   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
-//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]
+//         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--ref-walk] [--stats]
 //         [--devices 0-7 | 0,2,5] [--partition rows|samples]     several GPUs of the node (rt_comm_*: RCCL gather / sum-reduce)
 #include <chrono>
 #include <cstdio>
@@ -18,7 +18,7 @@
 
 static int usage() {
     fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
-                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--stats]\n"
+                    "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--ref-walk] [--stats]\n"
                     "             [--devices 0-7|0,2,5] [--partition rows|samples]\n");
     return 2;
 }
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
     unsigned seed = 37811;
     std::vector<int> devices;
     int partition = RT_PART_ROWS;
-    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false;
+    bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false, ref_walk = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
         else if (a == "--volume") volume = true;
         else if (a == "--fast-bvh") fast_bvh = true;
         else if (a == "--raymarch") raymarch = true;
+        else if (a == "--ref-walk") ref_walk = true;   // every ray on the reference's own tree (RT_F_REFWALK; same image, slower)
         else if (a == "--stats") want_stats = true;
         else return usage();
     }
@@ -104,7 +105,7 @@ int main(int argc, char** argv) {
     p.max_bounces = bounces;
     p.flags = RT_F_SKYBOX | RT_F_ANTIALIAS | RT_F_DEFOCUS | (bvh ? RT_F_BVH : 0) | (spheres ? RT_F_SPHERES : 0) |
               (wavefront ? RT_F_WAVEFRONT : 0) | (lockstep ? RT_F_LOCKSTEP : 0) | (volume ? RT_F_VOLUME : 0) |
-              (raymarch ? RT_F_RAYMARCH : 0) | (want_stats ? RT_F_STATS : 0);
+              (raymarch ? RT_F_RAYMARCH : 0) | (want_stats ? RT_F_STATS : 0) | (ref_walk ? RT_F_REFWALK : 0);
     p.seed = seed;
     p.sample_begin = 0;
     p.sample_count = spp > 0 ? spp : cam.num_samples;
