@@ -2032,7 +2032,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             shorts.resize((size_t)np - 1);  // the node that splits [lo, hi) at mid is shorts[mid - 1]: no two nodes share a split point
             std::atomic<int> deepest_short{0};
             const int NB = 32;              // bins of the centroid range per axis
-            const int short_sweep_max = np <= (1 << 18) ? RT_SHORT_SWEEP_MAX : 64;
+            int short_sweep_max = np <= (1 << 18) ? RT_SHORT_SWEEP_MAX : 64;
+            if (const char* e = getenv("RT_SHORT_SWEEP_MAX")) short_sweep_max = std::max(2, atoi(e));  // experiments only
             struct Bins { float bb[3][32][6], bw[3][32]; int bn[3][32]; float ub[6], cmn[3], cmx[3]; };
             // A pass over prims[lo, hi) in fixed chunks of 2^16, the chunks' results folded in chunk order: the same result on
             // any number of threads (the float sums included); big nodes only, where the recursion has few branches yet.
@@ -2079,7 +2080,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 float best = 3e38f;
                 float cmn[3], cmx[3];
                 if (n <= short_sweep_max) {  // every split position along every axis
-                    float suffix[2 * (RT_SHORT_SWEEP_MAX + 1)];
+                    std::vector<float> suffix(2 * ((size_t)n + 1));
                     memcpy(box, kEmpty, 6 * sizeof(float));
                     for (int k = 0; k < 3; k++) { cmn[k] = 3e38f; cmx[k] = -3e38f; }
                     for (int p = lo; p < hi; p++) {
