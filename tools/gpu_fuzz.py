@@ -12,11 +12,19 @@ rt = ob.rt; ob.lib()
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 os.environ["RT_SUB_MIN_TRIS"] = "0"
+# how the shortcut tree is built, scene after scene: over runs (default) / over whole leaves / over a frontier 1-3 levels below the leaves /
+# over single triangles without sub-trees (what scenes too small for sub-trees get)
+SHORTCUT_MODES = [{}, {"RT_SHORT_LEAVES": "1", "RT_SHORT_CUT": "0"}, {"RT_SHORT_LEAVES": "1", "RT_SHORT_CUT": None}, {"RT_SUB_MIN_TRIS": "100000000"}]
 gpu = rt.Renderer(0)
 bad = 0
 t_start = time.time()
 for it in range(n_scenes):
     rng = np.random.default_rng(seed0 + it)
+    for k_ in ("RT_SHORT_LEAVES", "RT_SHORT_CUT"):
+        os.environ.pop(k_, None)
+    os.environ["RT_SUB_MIN_TRIS"] = "0"
+    for k_, v_ in SHORTCUT_MODES[it % 4].items():
+        os.environ[k_] = v_ if v_ is not None else str(1 + it // 4 % 3)
     kind = rng.integers(0, 6)
     n = int(rng.integers(30, 6000))
     scale = float(10.0 ** rng.uniform(-3, 3))
