@@ -2059,8 +2059,17 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 init(total);
                 for (int c = 0; c < nch; c++) fold(total, part[(size_t)c]);
             };
-            auto less_on = [](int axis) {
-                return [axis](const ShortPrim& a, const ShortPrim& b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.node < b.node); };
+            auto less_on = [](int axis) {  // by centroid, ties by what hangs there: on the floats' bits made monotonic, a total order whatever the values (NaN included)
+                return [axis](const ShortPrim& a, const ShortPrim& b) {
+                    auto key = [](float f) {
+                        f += 0.0f;  // (-0 -> +0)
+                        uint32_t u;
+                        memcpy(&u, &f, 4);
+                        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    };
+                    const uint32_t ka = key(a.c[axis]), kb = key(b.c[axis]);
+                    return ka < kb || (ka == kb && a.node < b.node);
+                };
             };
             // returns the entry of the node over prims[lo, hi) standing at level d (root: 0) and its padded box
             auto build_short = [&](auto&& self, int lo, int hi, int d, float* box) -> int {

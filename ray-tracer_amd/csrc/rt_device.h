@@ -54,6 +54,10 @@ namespace rtd {
 // the slack rule guarantees the shortcut walk has tested.  A ray that is not certified (a hit on an edge shared by two
 // leaves, coincident geometry) walks the reference's tree from the root; rays with a non-finite 1/d or from beyond
 // cull_far never try the shortcut.  RT_F_STATS counts the reference's walk and therefore walks it (RT_F_REFWALK).
+// What hangs below the shortcut tree (rt_core.hip, build_layout): the RUNS of the item stream (triangles tested one after
+// the other up to a 'last' flag); in a scene with more than 2^20 runs what stands a few levels below each reference leaf
+// in its sub-tree (the walk then continues into the sub-tree); in a scene too small for sub-trees its SINGLE triangles
+// (short_single: a shortcut search leaves a leaf after one test, whatever the 'last' flags say).
 // LEAF SUB-TREES.  The reference tests EVERY triangle of a leaf, in array order, and a later triangle replaces the
 // hit only if strictly closer (main.cu:249-264): the leaf's result is the closest hit below the distance the ray
 // arrived with and, among equals, the one first in the array -- which does not depend on the order of the tests, and
