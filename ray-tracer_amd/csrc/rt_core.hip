@@ -252,6 +252,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_REGEN_MIN_TINY
 #define RT_REGEN_MIN_TINY 48    // vertex-pass vote there (40 / 44 / 48 / 52 / 56: 100.5 / 97.6 / 97.3 / 97.7 / 101.1 ms)
 #endif
+#ifndef RT_REGEN_MIN_COOP
+#define RT_REGEN_MIN_COOP 48    // ... in scenes whose vertex passes run the wave-cooperative light loop (scene2_is.txt 32 spp: 40 / 44 / 48 / 52 / 56 = 69.4 / 68.1 / 67.4 / 67.4 / 69.0 ms)
+#endif
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
                        // more bytes at the HBM: 3.18 vs 2.93 GB per frame of scene.txt; profiles/r02_ab.txt)
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     for (;;) {
         const unsigned long long mNeed = __ballot((unsigned)(t.cur + 2) < 2u);  // RT_TRAV_DONE or RT_LANE_NEW
         const unsigned long long mTrav = __ballot(t.cur >= 0);
-        if (__popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : RT_REGEN_MIN) || mTrav == 0) {
+        if (__popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : COOP ? RT_REGEN_MIN_COOP : RT_REGEN_MIN) || mTrav == 0) {
             if (mNeed == 0) break;  // every lane idle: no paths left
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
