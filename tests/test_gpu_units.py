@@ -234,6 +234,13 @@ def test_spheres_brute_force_no_aa_no_skybox(ob, rt, gpu, tmp_path, mode):
         o, ost = ob.render(sc, p, n_threads=4)
         assert np.array_equal(gpu.readback(), o), flags
         assert (st.rays, st.tri_tests, st.hits, st.texel_fetches) == (ost.rays, ost.tri_tests, ost.hits, ost.texel_fetches)
+        if mode == "megakernel":    # without counters the searches go down the shortcut tree (single triangles here): spheres come after it
+            q = rt.RenderParams.from_buffer_copy(p); q.flags = flags | m
+            gpu.reset(); gpu.render(q)
+            assert np.array_equal(gpu.readback(), o), ("shortcut", flags)
+            q.flags |= rt.F_STATS | rt.F_SHORTCUT_STATS
+            gpu.reset(); ss = gpu.render(q)
+            assert np.array_equal(gpu.readback(), o) and (ss.rays, ss.hits, ss.texel_fetches) == (ost.rays, ost.hits, ost.texel_fetches)
 
 
 @pytest.mark.parametrize("mode", ["wavefront", "megakernel", "lockstep"])
