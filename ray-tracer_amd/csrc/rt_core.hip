@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     // the material table behind the stacks (n_mats_lds = 0: too many materials, they stay in device memory)
     const int mats_lds = n_mats_lds > 0 ? (int)(RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16) : -1;
     for (int i = threadIdx.x; i < 3 * n_mats_lds; i += 64 * RT_MEGA_WAVES) rt_lds[mats_lds + i] = sc.mats[i];
+    // COOP: behind the material table RT_LQ_CAP words per wave for the light loop's queue (wave_light_pdf_q)
+    [[maybe_unused]] volatile unsigned* lqueue = (volatile unsigned*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16 + 3 * (size_t)n_mats_lds) + wave * RT_LQ_CAP;
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 }
             }
             if (COOP && __ballot(lq.pending)) {  // material type 5 with many lights: its light loop, with the whole wave (rt_device.h)
-                const float pdf_light = wave_light_pdf<STATS>(sc, lq, cn);
+                const float pdf_light = wave_light_pdf_q<STATS>(sc, lq, cn, lqueue);
                 if (lq.pending) {
                     finish_type5(sc, ray, lq, pdf_light);
                     ray.d = normalize_keep(ray.d);  // main.cu:361
@@ -2464,7 +2466,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      in that order, see wave_light_pdf).
     const int nl = s->n_light_tris;
     const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
-    const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 20;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
+    const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 4 * RT_LIGHT_PLANES;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
     const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
     std::vector<float>& lights = L.lights;
     lights.assign(light_place_off + (size_t)((std::max(nl, 1) + 3) & ~3), 0.f);
@@ -2520,12 +2522,17 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         const H3 cr = hcross(e1, e2);
         const H3 nrm = hnormalize(cr);
         const float area = 0.5f * hlen(cr);
-        float Lr[20];
+        float Lr[24];
+        {   // bounding sphere of the triangle about its centroid, radius padded (wave_light_pdf_q drops a light only if the ray misses it)
+            const H3 cen{(p1.x + p2.x + p3.x) * (1.0f / 3.0f), (p1.y + p2.y + p3.y) * (1.0f / 3.0f), (p1.z + p2.z + p3.z) * (1.0f / 3.0f)};
+            const float r = std::max(hlen(hsub(p1, cen)), std::max(hlen(hsub(p2, cen)), hlen(hsub(p3, cen))));
+            Lr[20] = cen.x; Lr[21] = cen.y; Lr[22] = cen.z; Lr[23] = r * 1.001f + box_pad;
+        }
         Lr[0] = p1.x; Lr[1] = p1.y; Lr[2] = p1.z; Lr[3] = e1.x; Lr[4] = e1.y; Lr[5] = e1.z;
         Lr[6] = e2.x; Lr[7] = e2.y; Lr[8] = e2.z; Lr[9] = nrm.x; Lr[10] = nrm.y; Lr[11] = nrm.z;
         Lr[12] = area; Lr[13] = p2.x; Lr[14] = p2.y; Lr[15] = p2.z; Lr[16] = p3.x; Lr[17] = p3.y; Lr[18] = p3.z;
         Lr[19] = i2f(i);                                    // the light's place in the reference's list
-        for (int k = 0; k < 20; k++) lights[RT_LIGHT_F4(j, k / 4) * 4 + (size_t)(k % 4)] = Lr[k];  // plane by plane per group (rt_device.h)
+        for (int k = 0; k < 24; k++) lights[RT_LIGHT_F4(j, k / 4) * 4 + (size_t)(k % 4)] = Lr[k];  // plane by plane per group (rt_device.h)
         lights[light_place_off + (size_t)i] = i2f(j);
         float* B = &lights[light_box_off + (size_t)(j / RT_LIGHT_GROUP) * 8];
         for (int k = 0; k < 3; k++) {
@@ -2755,7 +2762,8 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     // (shortcut walk: a search that is not certified walks the reference's tree with the same stack)
     t.stack_entries = std::max(fast ? std::max(c->bvh_depth, c->short_depth) : c->bvh_depth, 1);
     t.n_mats_lds = (with_mats && c->sc.n_mats <= RT_LDS_MATS_MAX && !getenv("RT_NO_LDS_MATS")) ? c->sc.n_mats : 0;
-    const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48;
+    const size_t queue_bytes = (with_mats && c->sc.n_lights >= RT_LIGHTS_COOP_MIN) ? (size_t)waves * RT_LQ_CAP * 4 : 0;  // the light loop's queue
+    const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48 + queue_bytes;
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only

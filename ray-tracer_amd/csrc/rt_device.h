@@ -127,7 +127,8 @@ struct Params {
 #ifndef RT_LIGHT_GROUP
 #define RT_LIGHT_GROUP 16  // (8 / 16 / 32 measured: profiles/r02_ab.txt)
 #endif
-#define RT_LIGHT_F4(j, p) ((((size_t)(j) / RT_LIGHT_GROUP) * 5 + (p)) * RT_LIGHT_GROUP + (size_t)(j) % RT_LIGHT_GROUP)
+#define RT_LIGHT_PLANES 6  // five float4 of the record + (centre, padded radius) of the triangle's bounding sphere
+#define RT_LIGHT_F4(j, p) ((((size_t)(j) / RT_LIGHT_GROUP) * RT_LIGHT_PLANES + (p)) * RT_LIGHT_GROUP + (size_t)(j) % RT_LIGHT_GROUP)
 #define RT_STACK_ENTRIES 24   // per-lane LDS stack depth (a depth-D tree needs D entries here)
 #define RT_WAVES_PER_BLOCK 4
 
@@ -1159,7 +1160,7 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
                 if (gs >= 0 && i < sc.n_lights) {
                     if (STATS) cn.dev_lights++;
                     // (group gs, light sub: plane p of the group is 16 RT_LIGHT_GROUP contiguous bytes)
-                    const float4* L = sc.lights + ((size_t)(base / RT_LIGHT_GROUP + gs) * 5) * RT_LIGHT_GROUP + sub;
+                    const float4* L = sc.lights + ((size_t)(base / RT_LIGHT_GROUP + gs) * RT_LIGHT_PLANES) * RT_LIGHT_GROUP + sub;
                     const float4 l0 = L[0], l1 = L[RT_LIGHT_GROUP], l2 = L[2 * RT_LIGHT_GROUP], l3 = L[3 * RT_LIGHT_GROUP];
                     term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w),
                                     l3.x) / (float)sc.n_lights;
@@ -1172,6 +1173,115 @@ __device__ __forceinline__ float wave_light_pdf(const Scene& sc, const LightQuer
             if (lane == ow) { result = acc; nonzero = cnt; }
         }
     }
+    // three or more nonzero terms: their sum depends on the order; form it in the reference's
+    for (unsigned long long m = __ballot(q.pending && nonzero > 2); m; m &= m - 1) {
+        const int ow = __ffsll((long long)m) - 1;
+        const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
+        const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
+        const float exact = wave_light_pdf_ordered<STATS>(sc, hp, og, cn);
+        if (lane == ow) result = exact;
+    }
+    if (STATS && q.pending) cn.lights += (uint32_t)sc.n_lights;
+    return result;
+}
+
+// wave_light_pdf in two phases (rt_render_paths_kernel).  Most lights of a marked group are missed by the query's ray, and
+// the triangle test with its correctly rounded divisions is what the loop spends its instructions on.  Phase one: the 64
+// lanes test the ray against the BOUNDING SPHERES of 64 lights (one 16-byte load, a dozen instructions; the radius is
+// padded and the comparison has slack for its own cancellation, so a light the ray can hit is never dropped) and the
+// lights that pass are queued, (owner lane, light), in `queue` (RT_LQ_CAP words of LDS of this wave).  Phase two: whenever
+// 64 are queued, and at the end, each lane runs the triangle test of one queued pair -- whatever query it belongs to --
+// and a nonzero term goes to the registers of the lane that owns the query.  Same terms, same sums as wave_light_pdf.
+#define RT_LQ_CAP 128
+template <bool STATS>
+__device__ __forceinline__ float wave_light_pdf_q(const Scene& sc, const LightQuery& q, Counters& cn, volatile unsigned* queue) {
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / RT_LIGHT_GROUP, sub = lane % RT_LIGHT_GROUP;
+    float result = 0.0f;
+    int nonzero = 0;  // nonzero terms of this lane's query so far
+    int count = 0;    // queued pairs (wave-uniform), < 64 between appends
+    BoxRay br;
+    br.set(q.hitPos, q.outgoing);
+    auto run_queued = [&](int n) {  // the first n <= 64 queued pairs, one per lane
+        const unsigned c = lane < n ? queue[lane] : ((unsigned)lane << 24);
+        const int ow = (int)(c >> 24), i = (int)(c & 0xffffffu);
+        const f3 hp = mk(__shfl(q.hitPos.x, ow, 64), __shfl(q.hitPos.y, ow, 64), __shfl(q.hitPos.z, ow, 64));
+        const f3 og = mk(__shfl(q.outgoing.x, ow, 64), __shfl(q.outgoing.y, ow, 64), __shfl(q.outgoing.z, ow, 64));
+        float term = 0.0f;
+        if (lane < n) {
+            if (STATS) cn.dev_lights++;
+            const float4 l0 = sc.lights[RT_LIGHT_F4(i, 0)], l1 = sc.lights[RT_LIGHT_F4(i, 1)], l2 = sc.lights[RT_LIGHT_F4(i, 2)],
+                         l3 = sc.lights[RT_LIGHT_F4(i, 3)];
+            term = itri_pdf(hp, og, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w), l3.x) /
+                   (float)sc.n_lights;
+        }
+        for (unsigned long long h = __ballot(term != 0.0f); h; h &= h - 1) {
+            const int l = __ffsll((long long)h) - 1;
+            const int o = __builtin_amdgcn_readlane(ow, l);
+            const float tv = lane_f(term, l);
+            if (lane == o) {  // (meaningful while nonzero <= 2: those commute; beyond, the query is summed again below)
+                result += tv;
+                nonzero++;
+            }
+        }
+    };
+    for (int base = 0; base < sc.n_lights; base += RT_LIGHT_CHUNK) {
+        const int n_groups = min(64, (sc.n_lights - base + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP);
+        const float4* B = sc.light_boxes + 2 * (base / RT_LIGHT_GROUP);
+        unsigned long long mine = 0;
+        if (q.pending) {
+            if (fmaxf(fabsf(q.hitPos.x), fmaxf(fabsf(q.hitPos.y), fabsf(q.hitPos.z))) <= sc.cull_far) {
+                for (int g = 0; g < n_groups; g++)
+                    if (br.may_reach(B[2 * g], B[2 * g + 1])) mine |= 1ull << g;
+            } else {  // too far out for the padding of the boxes to cover the rounding of the slab test: every group
+                mine = n_groups >= 64 ? ~0ull : (1ull << n_groups) - 1;
+            }
+        }
+        for (unsigned long long m = __ballot(mine != 0); m; m &= m - 1) {
+            const int ow = __ffsll((long long)m) - 1;
+            const f3 hp = mk(lane_f(q.hitPos.x, ow), lane_f(q.hitPos.y, ow), lane_f(q.hitPos.z, ow));
+            const f3 og = mk(lane_f(q.outgoing.x, ow), lane_f(q.outgoing.y, ow), lane_f(q.outgoing.z, ow));
+            const float og2 = len2(og);
+            // (from beyond cull_far the spheres' padding does not cover the rounding either: every light of the group passes)
+            const bool far = !(fmaxf(fabsf(hp.x), fmaxf(fabsf(hp.y), fabsf(hp.z))) <= sc.cull_far);
+            unsigned long long gm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), ow) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((int)mine, ow);
+            while (gm) {
+                int g[64 / RT_LIGHT_GROUP];
+#pragma unroll
+                for (int k = 0; k < 64 / RT_LIGHT_GROUP; k++) {
+                    g[k] = gm ? __ffsll((long long)gm) - 1 : -1;
+                    gm &= gm - 1;
+                }
+                int gs = g[0];
+#pragma unroll
+                for (int k = 1; k < 64 / RT_LIGHT_GROUP; k++) gs = slot == k ? g[k] : gs;
+                const int i = base + gs * RT_LIGHT_GROUP + sub;
+                bool pass = false;
+                if (gs >= 0 && i < sc.n_lights) {
+                    const float4 sp = sc.lights[((size_t)(base / RT_LIGHT_GROUP + gs) * RT_LIGHT_PLANES + 5) * RT_LIGHT_GROUP + sub];
+                    const f3 v = mk(sp.x, sp.y, sp.z) - hp;
+                    const float b = dot(v, og), v2 = len2(v), r2 = sp.w * sp.w;
+                    // squared distance of the centre from the ray's LINE, times |og|^2, against the radius; 4e-7 v2: the rounding of
+                    // v2 og2 - b^2 itself.  Behind the origin (b < 0) only a sphere that holds the origin can be hit.
+                    pass = far || ((v2 * og2 - b * b <= r2 * og2 + 4e-7f * v2 * og2) && (b >= 0.0f || v2 <= r2));
+                }
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+                    if (pass) queue[count + (int)rank] = ((unsigned)ow << 24) | (unsigned)i;
+                    count += __popcll(pm);
+                    if (count >= 64) {
+                        run_queued(64);
+                        const unsigned moved = lane < count - 64 ? queue[64 + lane] : 0u;
+                        if (lane < count - 64) queue[lane] = moved;
+                        count -= 64;
+                    }
+                }
+            }
+        }
+    }
+    if (count) run_queued(count);
     // three or more nonzero terms: their sum depends on the order; form it in the reference's
     for (unsigned long long m = __ballot(q.pending && nonzero > 2); m; m &= m - 1) {
         const int ow = __ffsll((long long)m) - 1;
