@@ -26,6 +26,19 @@
 extern "C" {
 #endif
 
+/* ---- ABI version --------------------------------------------------------
+ * rt_render_stats and rt_layout_info grow at the END from round to round.  A caller says how large ITS struct is and
+ * the library writes at most that many bytes: rt_render_v2 / rt_comm_render_v2 / rt_layout_get_v2 take the size,
+ * and a C caller that includes this header gets them through the function-like macros below, with sizeof of the struct
+ * it was compiled with.  The plain symbols rt_render / rt_comm_render / rt_layout_get stay exported for binaries built
+ * against an older rt.h and fill only the fields that header had (RT_*_V1_SIZE / _V2_SIZE bytes).
+ * rt_abi_version() = RT_ABI_VERSION of the library that is loaded. */
+#define RT_ABI_VERSION 3
+#define RT_RENDER_STATS_V1_SIZE 88 /* round 1: kernel_ms .. trace_launches */
+#define RT_RENDER_STATS_V2_SIZE 128 /* round 2: + dev_inner_visits .. shortcut_rewalks (what rt_comm_render was born with) */
+#define RT_LAYOUT_INFO_V1_SIZE 28  /* round 1: n_inner .. cull_far */
+int rt_abi_version(void);
+
 /* ---- status codes ------------------------------------------------------- */
 typedef enum rt_status {
     RT_OK = 0,
@@ -206,7 +219,11 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
  * params->sample_count samples per pixel to the raw-sum accumulators
  * (re-entrant: progressive batches and sample slices).  Blocking.
  * stats may be NULL. */
-int rt_render(rt_context* ctx, const rt_render_params* params, rt_render_stats* stats);
+int rt_render(rt_context* ctx, const rt_render_params* params, rt_render_stats* stats); /* round 1's symbol: fills RT_RENDER_STATS_V1_SIZE bytes */
+int rt_render_v2(rt_context* ctx, const rt_render_params* params, rt_render_stats* stats, size_t stats_size);
+#ifndef RT_NO_SIZED_MACROS
+#define rt_render(ctx, params, stats) rt_render_v2((ctx), (params), (stats), sizeof(rt_render_stats))
+#endif
 
 /* Replaces the D2H copy src/main.cu:500-501 (and, with RT_READ_TONEMAPPED,
  * the `/numSamples` + toneMap of main.cu:392-406 that the reference does
@@ -287,11 +304,18 @@ int rt_comm_size(const rt_comm* comm);
 int rt_comm_transport(const rt_comm* comm);               /* the transport in use (RT_COMM_LOCAL if librccl could not be loaded) */
 rt_context* rt_comm_context(rt_comm* comm, int rank);     /* owned by the comm */
 int rt_comm_upload_scene(rt_comm* comm, const rt_scene_desc* scene);   /* replicated on every device */
-int rt_comm_render(rt_comm* comm, const rt_render_params* params, int partition, int band_rows, rt_render_stats* stats);
+int rt_comm_render(rt_comm* comm, const rt_render_params* params, int partition, int band_rows, rt_render_stats* stats); /* round 2's symbol: fills RT_RENDER_STATS_V2_SIZE bytes */
+int rt_comm_render_v2(rt_comm* comm, const rt_render_params* params, int partition, int band_rows, rt_render_stats* stats, size_t stats_size);
+#ifndef RT_NO_SIZED_MACROS
+#define rt_comm_render(comm, params, partition, band_rows, stats) rt_comm_render_v2((comm), (params), (partition), (band_rows), (stats), sizeof(rt_render_stats))
+#endif
 int rt_comm_reduce_sum(rt_comm* comm);    /* the combine steps alone (rt_comm_render calls them) */
 int rt_comm_gather_rows(rt_comm* comm);
 int rt_comm_reset(rt_comm* comm);
 int rt_comm_readback(rt_comm* comm, float* rgb, size_t n_floats, int mode);   /* the root's full image, RT_READ_* */
+/* Combine steps of this comm that went through RCCL so far (ncclReduce calls; grouped ncclSend / ncclRecv gathers).  With
+ * the RCCL transport a comm of ONE rank still runs both: the reduce in place, the gather as a send to itself. */
+int rt_comm_rccl_calls(const rt_comm* comm, uint64_t* reduces, uint64_t* sendrecvs);
 /* Host-side statements of the two combine steps, no device needed (what the CPU tests check the index arithmetic
  * and the summation order against): rows of `rank` under the band interleave (returns their number; rows may be
  * NULL), the de-interleave of band-packed buffers, the rank-ordered sum. */
@@ -324,7 +348,11 @@ typedef struct rt_layout_info {
     int32_t short_cut;    /* huge scenes: levels below the reference's leaves at which the shortcut tree's leaves stand */
 } rt_layout_info;
 int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
-int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places);
+int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places); /* round 1's symbol: fills RT_LAYOUT_INFO_V1_SIZE bytes */
+int rt_layout_get_v2(const rt_layout* layout, rt_layout_info* info, size_t info_size, const float** items, const int32_t** places);
+#ifndef RT_NO_SIZED_MACROS
+#define rt_layout_get(layout, info, items, places) rt_layout_get_v2((layout), (info), sizeof(rt_layout_info), (items), (places))
+#endif
 void rt_layout_destroy(rt_layout* layout);
 
 /* Test hook: evaluate device-side primitives on n host records.

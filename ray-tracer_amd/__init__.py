@@ -105,7 +105,9 @@ RT_SYMBOLS = ["rt_create", "rt_destroy", "rt_last_error", "rt_upload_scene", "rt
               "rt_trace_rays", "rt_trace_rays_noalloc", "rt_debug_op", "rt_shade_hits", "rt_layout_create", "rt_layout_get", "rt_layout_destroy",
               "rt_comm_create", "rt_comm_destroy", "rt_comm_last_error", "rt_comm_size", "rt_comm_transport", "rt_comm_context",
               "rt_comm_upload_scene", "rt_comm_render", "rt_comm_reduce_sum", "rt_comm_gather_rows", "rt_comm_reset",
-              "rt_comm_readback", "rt_band_rows_of_rank", "rt_host_gather_rows", "rt_host_reduce_sum"]
+              "rt_comm_readback", "rt_band_rows_of_rank", "rt_host_gather_rows", "rt_host_reduce_sum",
+              "rt_abi_version", "rt_render_v2", "rt_comm_render_v2", "rt_layout_get_v2", "rt_comm_rccl_calls"]
+ABI_VERSION = 3
 SCENE_SYMBOLS = ["rt_scene_last_error", "rt_scene_load", "rt_scene_from_records", "rt_scene_synth_field",
                  "rt_scene_free", "rt_scene_get_desc", "rt_scene_get_camera", "rt_scene_bvh_depth",
                  "rt_bvh_build", "rt_obj_load", "rt_noise_texture", "rt_image_load", "rt_image_save",
@@ -169,7 +171,10 @@ def core_lib() -> C.CDLL:
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
         L.rt_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
-        L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(RenderStats)]
+        L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]          # round 1's symbol (88-byte stats)
+        L.rt_render_v2.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_size_t]
+        if L.rt_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"librt_amd.so speaks ABI {L.rt_abi_version()}, this binding {ABI_VERSION}: run `make`")
         L.rt_readback.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_int]
         L.rt_readback_rgb8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rt_reset_accum.argtypes = [C.c_void_p]
@@ -184,7 +189,8 @@ def core_lib() -> C.CDLL:
         L.rt_debug_op.argtypes = [C.c_void_p, C.c_int, _fp, C.c_size_t, _fp, C.POINTER(RenderParams)]
         L.rt_shade_hits.argtypes = [C.c_void_p, _fp, C.c_size_t, C.c_uint32, _fp]
         L.rt_layout_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
-        L.rt_layout_get.argtypes = [C.c_void_p, C.POINTER(LayoutInfo), C.POINTER(_fp), C.POINTER(_ip)]
+        L.rt_layout_get.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_fp), C.POINTER(_ip)]  # round 1's symbol (28-byte info)
+        L.rt_layout_get_v2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(_fp), C.POINTER(_ip)]
         L.rt_layout_destroy.argtypes = [C.c_void_p]
         L.rt_layout_destroy.restype = None
         L.rt_comm_create.argtypes = [C.POINTER(C.c_void_p), _ip, C.c_int, C.c_int]
@@ -197,7 +203,9 @@ def core_lib() -> C.CDLL:
         L.rt_comm_context.argtypes = [C.c_void_p, C.c_int]
         L.rt_comm_context.restype = C.c_void_p
         L.rt_comm_upload_scene.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
-        L.rt_comm_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_int, C.POINTER(RenderStats)]
+        L.rt_comm_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_int, C.c_void_p]  # round 2's symbol
+        L.rt_comm_render_v2.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.rt_comm_rccl_calls.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.rt_comm_reduce_sum.argtypes = [C.c_void_p]
         L.rt_comm_gather_rows.argtypes = [C.c_void_p]
         L.rt_comm_reset.argtypes = [C.c_void_p]
@@ -381,7 +389,7 @@ def device_layout(scene: "Scene"):
     try:
         info = LayoutInfo()
         items_p, places_p = _fp(), _ip()
-        L.rt_layout_get(h, C.byref(info), C.byref(items_p), C.byref(places_p))
+        L.rt_layout_get_v2(h, C.byref(info), C.sizeof(info), C.byref(items_p), C.byref(places_p))
         n_items = info.n_inner + info.n_tris
         items = np.ctypeslib.as_array(items_p, shape=(max(n_items, 1), 16))[:n_items].copy()
         places = np.ctypeslib.as_array(places_p, shape=(max(info.n_tris, 1),))[:info.n_tris].copy()
@@ -425,7 +433,7 @@ class Renderer:
 
     def render(self, params: RenderParams, want_stats: bool = True) -> Optional[RenderStats]:
         st = RenderStats()
-        self._ck(self._L.rt_render(self._h, C.byref(params), C.byref(st)))
+        self._ck(self._L.rt_render_v2(self._h, C.byref(params), C.byref(st), C.sizeof(st)))
         self._rows = band_rows_of(params)
         self._width = params.cam.width
         return st if want_stats else None
@@ -520,12 +528,18 @@ class Comm:
 
     def render(self, params: RenderParams, partition: int, band_rows: int = 16) -> RenderStats:
         st = RenderStats()
-        self._ck(self._L.rt_comm_render(self._h, C.byref(params), partition, band_rows, C.byref(st)))
+        self._ck(self._L.rt_comm_render_v2(self._h, C.byref(params), partition, band_rows, C.byref(st), C.sizeof(st)))
         self._shape = (params.cam.height, params.cam.width)
         return st
 
     def reset(self):
         self._ck(self._L.rt_comm_reset(self._h))
+
+    def rccl_calls(self):
+        """(sum-reduces, send / receive gathers) of this comm that went through RCCL."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self._L.rt_comm_rccl_calls(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def readback(self, mode: int = READ_RAW_SUM) -> np.ndarray:
         out = np.empty(self._shape + (3,), np.float32)

@@ -6,6 +6,8 @@
 //   rtcli --scene scenes/scene.txt --asset-root assets --out out.png [--spp N] [--bounces N] [--size WxH]
 //         [--env file.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--ref-walk] [--stats]
 //         [--devices 0-7 | 0,2,5] [--partition rows|samples]     several GPUs of the node (rt_comm_*: RCCL gather / sum-reduce)
+//         [--json [--steps K] [--warmup W]]    with --devices: time K frames (render on every device + the collective) and
+//                                              print ONE JSON line with bench.py's fields instead of writing an image
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +21,7 @@
 static int usage() {
     fprintf(stderr, "usage: rtcli --scene FILE [--asset-root DIR] [--out FILE.png|.ppm|.hdr|.pfm] [--spp N] [--bounces N]\n"
                     "             [--size WxH] [--env FILE.hdr] [--hdr] [--seed N] [--spheres] [--no-bvh] [--wavefront|--lockstep] [--volume] [--raymarch] [--fast-bvh] [--ref-walk] [--stats]\n"
-                    "             [--devices 0-7|0,2,5] [--partition rows|samples]\n");
+                    "             [--devices 0-7|0,2,5] [--partition rows|samples] [--json [--steps K] [--warmup W]]\n");
     return 2;
 }
 
@@ -50,6 +52,8 @@ int main(int argc, char** argv) {
     unsigned seed = 37811;
     std::vector<int> devices;
     int partition = RT_PART_ROWS;
+    bool json = false;
+    int steps = 5, warmup = 1;
     bool hdr = false, spheres = false, bvh = true, wavefront = false, lockstep = false, volume = false, raymarch = false, fast_bvh = false, want_stats = false, ref_walk = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -75,6 +79,9 @@ int main(int argc, char** argv) {
         else if (a == "--raymarch") raymarch = true;
         else if (a == "--ref-walk") ref_walk = true;   // every ray on the reference's own tree (RT_F_REFWALK; same image, slower)
         else if (a == "--stats") want_stats = true;
+        else if (a == "--json") json = true;
+        else if (a == "--steps") steps = atoi(next());
+        else if (a == "--warmup") warmup = atoi(next());
         else return usage();
     }
     if (scene.empty()) return usage();
@@ -94,9 +101,10 @@ int main(int argc, char** argv) {
     }
     rt_scene_get_desc(hs, &desc);
     rt_scene_get_camera(hs, &cam);
-    printf("Number of triangles: %zu, BVH nodes: %d, materials: %zu\n", desc.n_tri_floats / RT_TRI_FLOATS, desc.n_nodes, desc.n_mats);
-    printf("num important tris: %d\n", desc.n_light_tris);          // main.cu:442
-    printf("Image data length: %zu\n", desc.n_tex_floats);          // main.cu:456
+    FILE* info = json ? stderr : stdout;  // (--json: stdout carries the one JSON line only)
+    fprintf(info, "Number of triangles: %zu, BVH nodes: %d, materials: %zu\n", desc.n_tri_floats / RT_TRI_FLOATS, desc.n_nodes, desc.n_mats);
+    fprintf(info, "num important tris: %d\n", desc.n_light_tris);          // main.cu:442
+    fprintf(info, "Image data length: %zu\n", desc.n_tex_floats);          // main.cu:456
 
     rt_render_params p;
     memset(&p, 0, sizeof(p));
@@ -121,9 +129,34 @@ int main(int argc, char** argv) {
             fprintf(stderr, "rt_comm_create failed: devices not usable (each id once, all present)\n");
             return 1;
         }
-        printf("%d devices, %s, transport %s\n", rt_comm_size(comm), partition == RT_PART_ROWS ? "image rows in bands of 16" : "sample slices",
+        fprintf(info, "%d devices, %s, transport %s\n", rt_comm_size(comm), partition == RT_PART_ROWS ? "image rows in bands of 16" : "sample slices",
                rt_comm_transport(comm) == RT_COMM_RCCL ? "RCCL" : "local copies");
         if (rt_comm_upload_scene(comm, &desc) != RT_OK) { fprintf(stderr, "upload: %s\n", rt_comm_last_error(comm)); return 1; }
+        if (json) {  // the native host's bench line: frames of (render on every device + ONE collective), wall clock around K of them
+            rt_render_params pc = p;
+            pc.flags |= RT_F_STATS;  // one untimed frame with counters: rays per frame (deterministic)
+            if (rt_comm_render(comm, &pc, partition, 16, &st) != RT_OK) { fprintf(stderr, "render: %s\n", rt_comm_last_error(comm)); return 1; }
+            const unsigned long long rays = st.rays, paths = st.paths;
+            for (int k = 0; k < warmup; k++)
+                if (rt_comm_reset(comm) != RT_OK || rt_comm_render(comm, &p, partition, 16, nullptr) != RT_OK) { fprintf(stderr, "render: %s\n", rt_comm_last_error(comm)); return 1; }
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < steps; k++)
+                if (rt_comm_reset(comm) != RT_OK || rt_comm_render(comm, &p, partition, 16, nullptr) != RT_OK) { fprintf(stderr, "render: %s\n", rt_comm_last_error(comm)); return 1; }
+            const double step_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (steps > 0 ? steps : 1);
+            uint64_t n_reduce = 0, n_sendrecv = 0;
+            rt_comm_rccl_calls(comm, &n_reduce, &n_sendrecv);
+            printf("{\"metric\": \"Mrays/sec (incl. bounces)\", \"value\": %.2f, \"unit\": \"Mrays/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
+                   "\"ms_per_step\": %.3f, \"higher_is_better\": true, \"scaling\": \"strong\", \"vs_baseline\": null, \"dtype\": \"f32\", "
+                   "\"data\": \"bundled scene geometry/textures, synthetic camera batch\", \"config\": {\"workload\": \"%s (%zu triangles)\", \"host\": \"rtcli (one process, one thread per device, rt_comm_*)\", "
+                   "\"width\": %d, \"height\": %d, \"spp_total\": %d, \"max_bounces\": %d, \"partition\": \"%s\", \"ranks_seen_by_rccl\": %d, \"transport\": \"%s\", "
+                   "\"rccl_reduces\": %llu, \"rccl_sendrecv_gathers\": %llu, \"rays_per_step\": %llu, \"paths_per_step\": %llu}}\n",
+                   rays / (step_ms * 1e3), rt_comm_size(comm), steps, warmup, step_ms, scene.c_str(), desc.n_tri_floats / RT_TRI_FLOATS, p.cam.width, p.cam.height,
+                   p.sample_count, p.max_bounces, partition == RT_PART_ROWS ? "rows" : "samples", rt_comm_size(comm),
+                   rt_comm_transport(comm) == RT_COMM_RCCL ? "rccl" : "local", (unsigned long long)n_reduce, (unsigned long long)n_sendrecv, rays, paths);
+            rt_comm_destroy(comm);
+            rt_scene_free(hs);
+            return 0;
+        }
         printf("begin rendering\n");
         const auto t0 = std::chrono::steady_clock::now();
         if (rt_comm_render(comm, &p, partition, 16, &st) != RT_OK) { fprintf(stderr, "render: %s\n", rt_comm_last_error(comm)); return 1; }

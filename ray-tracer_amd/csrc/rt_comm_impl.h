@@ -102,6 +102,7 @@ struct rt_comm {
     int64_t samples_done = 0;
     std::vector<int> n_rows;         // rows per rank of the last render (ROWS)
     bool pending = false;            // the ranks hold a rendered frame that has not been combined yet
+    unsigned long long rccl_reduces = 0, rccl_sendrecvs = 0;  // combine steps that went through RCCL (rt_comm_rccl_calls)
 };
 
 namespace {
@@ -119,6 +120,25 @@ int comm_err(rt_comm* c, int code, const std::string& msg) {
     do {                                                                                               \
         ncclResult_t r_ = (expr);                                                                      \
         if (r_ != ncclSuccess) return comm_err(c, RT_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// inside ncclGroupStart .. ncclGroupEnd: an error must close the group before it returns, or the next collective of
+// this thread is queued into a group nobody ends
+#define COMM_NCCL_G(c, expr)                                                                           \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) {                                                                       \
+            (void)g_rccl.GroupEnd();                                                                   \
+            return comm_err(c, RT_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));  \
+        }                                                                                              \
+    } while (0)
+#define COMM_HIP_G(c, expr)                                                                            \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (void)g_rccl.GroupEnd();                                                                   \
+            return comm_err(c, RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+        }                                                                                              \
     } while (0)
 
 int comm_grow(rt_comm* c, int device, float** buf, size_t* have, size_t need) {
@@ -257,7 +277,14 @@ rt_context* rt_comm_context(rt_comm* c, int rank) { return (c && rank >= 0 && ra
 
 int rt_comm_upload_scene(rt_comm* c, const rt_scene_desc* scene) {
     if (!c) return RT_ERR_INVALID;
-    return comm_parallel(c, [&](int r) { return rt_upload_scene(c->ctx[(size_t)r], scene); });
+    // the device layout (sub-trees, shortcut tree, light order) is built ONCE on all host threads; the ranks then only
+    // allocate and copy, each on its own thread
+    UploadTimer timer;
+    HostLayout L;
+    std::string err;
+    const int rc = build_layout(scene, L, err, timer);
+    if (rc != RT_OK) return comm_err(c, rc, err);
+    return comm_parallel(c, [&](int r) { UploadTimer t; return upload_built(c->ctx[(size_t)r], scene, L, t); });
 }
 
 int rt_comm_reset(rt_comm* c) {
@@ -278,13 +305,14 @@ int rt_comm_reduce_sum(rt_comm* c) {
     if (!c->pending || c->partition != RT_PART_SAMPLES) return comm_err(c, RT_ERR_INVALID, "no sample-sliced frame to combine");
     const size_t n = (size_t)c->width * c->height * 3;
     hipStream_t s0 = c->ctx[0]->stream;
-    if (c->transport == RT_COMM_RCCL && c->n > 1) {
+    if (c->transport == RT_COMM_RCCL) {  // (with ONE rank too: ncclReduce in place is then a no-op that still runs the transport)
         COMM_NCCL(c, g_rccl.GroupStart());
         for (int r = 0; r < c->n; r++) {
-            COMM_HIP(c, hipSetDevice(c->devices[(size_t)r]));
-            COMM_NCCL(c, g_rccl.Reduce(c->accum[(size_t)r], c->accum[(size_t)r], n, ncclFloat, ncclSum, 0, c->comms[(size_t)r], c->ctx[(size_t)r]->stream));
+            COMM_HIP_G(c, hipSetDevice(c->devices[(size_t)r]));
+            COMM_NCCL_G(c, g_rccl.Reduce(c->accum[(size_t)r], c->accum[(size_t)r], n, ncclFloat, ncclSum, 0, c->comms[(size_t)r], c->ctx[(size_t)r]->stream));
         }
         COMM_NCCL(c, g_rccl.GroupEnd());
+        c->rccl_reduces++;
         COMM_HIP(c, hipSetDevice(c->devices[0]));
     } else {  // LOCAL: ((a0 + a1) + a2) + ... on the root
         COMM_HIP(c, hipSetDevice(c->devices[0]));
@@ -309,22 +337,26 @@ int rt_comm_gather_rows(rt_comm* c) {
     if (!c->pending || c->partition != RT_PART_ROWS) return comm_err(c, RT_ERR_INVALID, "no row-partitioned frame to combine");
     const size_t rf = (size_t)c->width * 3;
     hipStream_t s0 = c->ctx[0]->stream;
-    for (int r = 1; r < c->n; r++) {
+    // RCCL with ONE rank: the root's rows take the transport's path too (a grouped ncclSend / ncclRecv to itself into
+    // its staging buffer), so that a one-GPU box runs the send / receive code; with peers the root's own rows stay put
+    const bool self_send = c->transport == RT_COMM_RCCL && c->n == 1;
+    for (int r = self_send ? 0 : 1; r < c->n; r++) {
         int rc = comm_grow(c, c->devices[0], &c->staging[(size_t)r], &c->staging_floats[(size_t)r], (size_t)c->n_rows[(size_t)r] * rf);
         if (rc != RT_OK) return rc;
     }
-    if (c->transport == RT_COMM_RCCL && c->n > 1) {
+    if (c->transport == RT_COMM_RCCL) {
         COMM_NCCL(c, g_rccl.GroupStart());
-        for (int r = 1; r < c->n; r++) {
+        for (int r = self_send ? 0 : 1; r < c->n; r++) {
             if (!c->n_rows[(size_t)r]) continue;
-            COMM_HIP(c, hipSetDevice(c->devices[(size_t)r]));
-            COMM_NCCL(c, g_rccl.Send(c->accum[(size_t)r], (size_t)c->n_rows[(size_t)r] * rf, ncclFloat, 0, c->comms[(size_t)r], c->ctx[(size_t)r]->stream));
+            COMM_HIP_G(c, hipSetDevice(c->devices[(size_t)r]));
+            COMM_NCCL_G(c, g_rccl.Send(c->accum[(size_t)r], (size_t)c->n_rows[(size_t)r] * rf, ncclFloat, 0, c->comms[(size_t)r], c->ctx[(size_t)r]->stream));
         }
-        COMM_HIP(c, hipSetDevice(c->devices[0]));
-        for (int r = 1; r < c->n; r++)
+        COMM_HIP_G(c, hipSetDevice(c->devices[0]));
+        for (int r = self_send ? 0 : 1; r < c->n; r++)
             if (c->n_rows[(size_t)r])
-                COMM_NCCL(c, g_rccl.Recv(c->staging[(size_t)r], (size_t)c->n_rows[(size_t)r] * rf, ncclFloat, r, c->comms[0], s0));
+                COMM_NCCL_G(c, g_rccl.Recv(c->staging[(size_t)r], (size_t)c->n_rows[(size_t)r] * rf, ncclFloat, r, c->comms[0], s0));
         COMM_NCCL(c, g_rccl.GroupEnd());
+        c->rccl_sendrecvs++;
     } else {
         COMM_HIP(c, hipSetDevice(c->devices[0]));
         for (int r = 1; r < c->n; r++)
@@ -337,7 +369,7 @@ int rt_comm_gather_rows(rt_comm* c) {
     for (int r = 0; r < c->n; r++) {
         const size_t cnt = (size_t)c->n_rows[(size_t)r] * rf;
         if (cnt)
-            hipLaunchKernelGGL(rt_rows_scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s0, r == 0 ? c->accum[0] : c->staging[(size_t)r],
+            hipLaunchKernelGGL(rt_rows_scatter_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s0, (r == 0 && !self_send) ? c->accum[0] : c->staging[(size_t)r],
                                c->full, c->d_rows + off, c->n_rows[(size_t)r], (int)rf);
         off += (size_t)c->n_rows[(size_t)r];
     }
@@ -348,7 +380,9 @@ int rt_comm_gather_rows(rt_comm* c) {
     return RT_OK;
 }
 
-int rt_comm_render(rt_comm* c, const rt_render_params* p, int partition, int band_rows, rt_render_stats* stats) {
+}  // extern "C"
+namespace {
+int comm_render_impl(rt_comm* c, const rt_render_params* p, int partition, int band_rows, rt_render_stats* stats) {
     if (!c || !p) return RT_ERR_INVALID;
     if (partition != RT_PART_ROWS && partition != RT_PART_SAMPLES) return comm_err(c, RT_ERR_INVALID, "unknown partition");
     if (p->cam.width <= 0 || p->cam.height <= 0 || p->sample_count < 0) return comm_err(c, RT_ERR_INVALID, "bad image size / sample count");
@@ -412,7 +446,10 @@ int rt_comm_render(rt_comm* c, const rt_render_params* p, int partition, int ban
         // (rt_render zeroes on a shape change by itself; the same shape twice in a row must start from zero too)
     }
     std::vector<rt_render_stats> st((size_t)c->n);
-    int rc = comm_parallel(c, [&](int r) { return rt_render(c->ctx[(size_t)r], &rp[(size_t)r], &st[(size_t)r]); });
+    // Every rank renders, THEN the one collective of the frame is issued (not from each rank's thread behind its own
+    // render): a rank whose render fails must not leave its peers blocked inside a collective it never joins, and a
+    // reduce cannot finish before its slowest input anyway.
+    int rc = comm_parallel(c, [&](int r) { return render_impl(c->ctx[(size_t)r], &rp[(size_t)r], &st[(size_t)r]); });
     if (rc != RT_OK) return rc;
     c->pending = true;
     rc = partition == RT_PART_ROWS ? rt_comm_gather_rows(c) : rt_comm_reduce_sum(c);
@@ -426,10 +463,33 @@ int rt_comm_render(rt_comm* c, const rt_render_params* p, int partition, int ban
             stats->paths += s.paths; stats->rays += s.rays; stats->inner_visits += s.inner_visits; stats->leaf_visits += s.leaf_visits;
             stats->tri_tests += s.tri_tests; stats->hits += s.hits; stats->texel_fetches += s.texel_fetches; stats->light_tests += s.light_tests;
             stats->dev_inner_visits += s.dev_inner_visits; stats->dev_lds_inner_visits += s.dev_lds_inner_visits; stats->dev_tri_tests += s.dev_tri_tests;
+            stats->dev_light_tests += s.dev_light_tests; stats->shortcut_rewalks += s.shortcut_rewalks;
             stats->iterations = std::max(stats->iterations, s.iterations);
             stats->trace_launches = std::max(stats->trace_launches, s.trace_launches);
         }
     }
+    return RT_OK;
+}
+}  // namespace
+extern "C" {
+
+int rt_comm_render_v2(rt_comm* c, const rt_render_params* p, int partition, int band_rows, rt_render_stats* stats, size_t stats_size) {
+    rt_render_stats full;
+    memset(&full, 0, sizeof(full));
+    const int rc = comm_render_impl(c, p, partition, band_rows, stats ? &full : nullptr);
+    if (stats) memcpy(stats, &full, std::min(stats_size, sizeof(full)));
+    return rc;
+}
+// The symbol round 2 exported: its callers hold round 2's struct.
+int rt_comm_render(rt_comm* c, const rt_render_params* p, int partition, int band_rows, rt_render_stats* stats) {
+    return rt_comm_render_v2(c, p, partition, band_rows, stats, RT_RENDER_STATS_V2_SIZE);
+}
+
+// Combine steps of this comm that went through RCCL so far: sum-reduces, grouped send / receive gathers.
+int rt_comm_rccl_calls(const rt_comm* c, uint64_t* reduces, uint64_t* sendrecvs) {
+    if (!c) return RT_ERR_INVALID;
+    if (reduces) *reduces = c->rccl_reduces;
+    if (sendrecvs) *sendrecvs = c->rccl_sendrecvs;
     return RT_OK;
 }
 

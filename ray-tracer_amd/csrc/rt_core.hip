@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#define RT_NO_SIZED_MACROS  // (this file DEFINES rt_render & co.; callers get them as sizeof-passing macros)
 #include "rt.h"
 #include "rt_device.h"
 #include "rt_pmath.h"
@@ -2579,13 +2580,10 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
 }
 }  // namespace
 
-int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
-    if (!c) return RT_ERR_INVALID;
-    UploadTimer timer;
-    HostLayout L;
-    std::string err;
-    int rc = build_layout(s, L, err, timer);
-    if (rc != RT_OK) return set_err(c, rc, err);
+// The device half of rt_upload_scene: allocations and copies of a layout that is built (rt_comm_upload_scene builds it
+// once for all its ranks).
+static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout& L, UploadTimer& timer) {
+    int rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const int nn = s->n_nodes;
     free_scene(c);
@@ -2634,6 +2632,16 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     return RT_OK;
 }
 
+int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
+    if (!c) return RT_ERR_INVALID;
+    UploadTimer timer;
+    HostLayout L;
+    std::string err;
+    const int rc = build_layout(s, L, err, timer);
+    if (rc != RT_OK) return set_err(c, rc, err);
+    return upload_built(c, s, L, timer);
+}
+
 // Host-side inspection of the device layout (include/rt.h): no device needed.
 struct rt_layout {
     HostLayout L;
@@ -2656,9 +2664,11 @@ int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf,
     return RT_OK;
 }
 
-int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items, const int32_t** places) {
+int rt_layout_get_v2(const rt_layout* h, rt_layout_info* info_out, size_t info_size, const float** items, const int32_t** places) {
     if (!h) return RT_ERR_INVALID;
-    if (info) {
+    if (info_out) {
+        rt_layout_info full, *info = &full;
+        memset(&full, 0, sizeof(full));
         info->n_inner = h->L.n_inner;
         info->n_sub = h->L.n_sub;
         info->n_tris = h->L.n_tris;
@@ -2672,10 +2682,16 @@ int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items,
         info->short_depth = h->L.short_depth;
         info->short_single = h->L.short_single ? 1 : 0;
         info->short_cut = h->L.short_cut;
+        memcpy(info_out, &full, std::min(info_size, sizeof(full)));
     }
     if (items) *items = h->L.items.data();
     if (places) *places = h->L.place.data();
     return RT_OK;
+}
+
+// The symbol round 1 exported: fills round 1's fields only.
+int rt_layout_get(const rt_layout* h, rt_layout_info* info, const float** items, const int32_t** places) {
+    return rt_layout_get_v2(h, info, RT_LAYOUT_INFO_V1_SIZE, items, places);
 }
 
 void rt_layout_destroy(rt_layout* h) { delete h; }
@@ -3054,7 +3070,9 @@ int render_wavefront(rt_context* c, const Params& P, float* accum, bool want_sta
 
 }  // namespace
 
-int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) {
+}  // extern "C"
+namespace {
+int render_impl(rt_context* c, const rt_render_params* p, rt_render_stats* stats) {
     if (!c) return RT_ERR_INVALID;
     if (!c->has_scene) return set_err(c, RT_ERR_NO_SCENE, "rt_render before rt_upload_scene");
     Params P;
@@ -3127,6 +3145,22 @@ int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) 
     }
     return RT_OK;
 }
+}  // namespace
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+// The caller says how large ITS rt_render_stats is: the library fills a struct of its own and copies that many bytes
+// (the structs only ever grow at the end), so a caller compiled against an older rt.h is never written past its struct.
+int rt_render_v2(rt_context* c, const rt_render_params* p, rt_render_stats* stats, size_t stats_size) {
+    rt_render_stats full;
+    memset(&full, 0, sizeof(full));
+    const int rc = render_impl(c, p, stats ? &full : nullptr);
+    if (stats) memcpy(stats, &full, std::min(stats_size, sizeof(full)));
+    return rc;
+}
+// The symbol round 1 exported: its callers hold round 1's struct (RT_RENDER_STATS_V1_SIZE bytes).
+int rt_render(rt_context* c, const rt_render_params* p, rt_render_stats* stats) { return rt_render_v2(c, p, stats, RT_RENDER_STATS_V1_SIZE); }
 
 int rt_resolve_device(rt_context* c, float* dev_out, size_t n_floats, int mode) {
     if (!c || !dev_out) return RT_ERR_INVALID;

@@ -1,6 +1,8 @@
 """rt_comm_* (include/rt.h: several GPUs from one process) through the C-ABI on ONE device: the LOCAL transport with
 three ranks sharing the device runs the same partition, the same kernels and the same de-interleave / summation as
-the RCCL transport on eight devices; the RCCL transport itself is exercised with the one rank a one-GPU box allows."""
+the RCCL transport on eight devices; the RCCL transport itself is exercised with the one rank a one-GPU box allows:
+ncclReduce in place and a grouped ncclSend / ncclRecv of the rank to itself really run (rt_comm_rccl_calls counts them).
+What no one-GPU box can show -- ncclReduce / ncclSend / ncclRecv BETWEEN devices -- stays unverified until an 8-GPU run."""
 import numpy as np
 import pytest
 
@@ -21,6 +23,7 @@ def test_rows_partition_gathered_image_is_bit_identical(rt, gpu, scenes, n_ranks
         img = comm.readback()
         assert np.array_equal(img, one)                               # keyed RNG: (pixel, sample) only
         assert (st.paths, st.rays, st.tri_tests, st.hits) == (st1.paths, st1.rays, st1.tri_tests, st1.hits)
+        assert (st.dev_tri_tests, st.shortcut_rewalks, st.dev_light_tests) == (st1.dev_tri_tests, st1.shortcut_rewalks, st1.dev_light_tests)
         comm.render(p, rt.PART_ROWS, band)                            # accumulates like rt_render: twice the sums
         assert np.array_equal(comm.readback(), one + one)
         avg = comm.readback(rt.READ_AVERAGE)
@@ -64,8 +67,9 @@ def test_sample_slices_summed_in_rank_order(rt, gpu, scenes, n_ranks):
 
 
 def test_rccl_transport_with_the_one_rank_this_box_has(rt, gpu, scenes):
-    """ncclCommInitAll / ncclReduce / the grouped send-recv path with a single rank: librccl loads, the communicator
-    is created on device 0 and both combine steps give the one-GPU image."""
+    """ncclCommInitAll, then with the single rank RCCL allows on one device: ncclReduce (in place, root 0) for the sample
+    slices and a grouped ncclSend / ncclRecv of the rank to itself for the rows -- both calls are really issued (the
+    comm counts them) and both combine steps give the one-GPU image.  Transfers between devices are NOT covered."""
     sc = scenes("scene_cornellbox.txt")
     gpu.upload(sc)
     p = rt.default_params(sc.camera, spp=2, width=64, height=48, max_bounces=4)
@@ -74,11 +78,16 @@ def test_rccl_transport_with_the_one_rank_this_box_has(rt, gpu, scenes):
     try:
         assert comm.transport == rt.COMM_RCCL, "librccl.so.1 did not load"
         comm.upload(sc)
+        assert comm.rccl_calls() == (0, 0)
         comm.render(p, rt.PART_SAMPLES)
         assert np.array_equal(comm.readback(), one)
+        assert comm.rccl_calls() == (1, 0)                            # ncclReduce ran
         comm.reset()
         comm.render(p, rt.PART_ROWS)
         assert np.array_equal(comm.readback(), one)
+        assert comm.rccl_calls() == (1, 1)                            # ... and the grouped self send / receive
+        comm.render(p, rt.PART_ROWS)                                  # accumulates: twice the sums, through the staging copy again
+        assert np.array_equal(comm.readback(), one + one) and comm.rccl_calls() == (1, 2)
     finally:
         comm.close()
     with pytest.raises(RuntimeError):                                 # RCCL wants one rank per device

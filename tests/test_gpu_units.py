@@ -798,3 +798,32 @@ def test_tiny_scene_with_its_triangles_in_lds(ob, rt, gpu, scenes, monkeypatch):
         assert (st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.hits) == (ost.rays, ost.inner_visits, ost.leaf_visits, ost.tri_tests, ost.hits)
         got.append((st.dev_inner_visits, st.dev_lds_inner_visits, st.dev_tri_tests))
     assert got[0] == got[1] and got[0][0] == got[0][1] > 0      # every inner item from the LDS either way
+
+
+def test_callers_of_an_older_header_are_not_written_past_their_struct(rt, gpu, scenes):
+    """ABI versioning (include/rt.h): rt_render_stats grew at the end in round 2.  The symbol round 1 exported, rt_render,
+    fills round 1's 88 bytes and nothing behind them; rt_render_v2 writes exactly the size the caller states."""
+    L = rt.core_lib()
+    assert L.rt_abi_version() == rt.ABI_VERSION
+    sc = scenes("scene_cornellbox.txt")
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=2, width=32, height=32, flags=rt.F_DEFAULT | rt.F_STATS)
+    full = gpu.render(p)                                               # the binding's own call: every field
+    assert full.rays > 0 and full.dev_tri_tests > 0 and C.sizeof(full) >= 128
+    ref = bytes(full)
+    for fn, size in ((lambda buf: L.rt_render(gpu._h, C.byref(p), buf), 88),
+                     (lambda buf: L.rt_render_v2(gpu._h, C.byref(p), buf, 96), 96),
+                     (lambda buf: L.rt_render_v2(gpu._h, C.byref(p), buf, 4096), C.sizeof(full))):
+        buf = (C.c_ubyte * 256)(*([0xA5] * 256))
+        assert fn(buf) == 0
+        got = bytes(buf)
+        assert got[8:size] == ref[8:size]                               # (bytes 0-7: kernel_ms, differs from call to call)
+        assert got[size:] == b"\xa5" * (256 - size)                     # nothing behind the caller's struct is touched
+    info = (C.c_ubyte * 128)(*([0xA5] * 128))
+    lay = C.c_void_p()
+    assert L.rt_layout_create(C.byref(sc.desc), C.byref(lay), None, 0) == 0
+    try:
+        assert L.rt_layout_get(lay, info, None, None) == 0              # round 1's symbol: 28 bytes
+        assert bytes(info)[28:] == b"\xa5" * 100 and bytes(info)[:4] != b"\xa5" * 4
+    finally:
+        L.rt_layout_destroy(lay)
