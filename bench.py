@@ -15,12 +15,15 @@ N > 1: one process per GPU.  Under torch.distributed.run the ranks come from the
 `python bench.py --gpus N`, bench.py starts the N ranks itself (a torch.distributed.run child process, before
 anything in this process touches the GPU) and exits with its code.
 
-Prints ONE JSON line on rank 0.  `roofline` names the limit that binds:
+Prints ONE JSON line on rank 0.  `roofline.frac` is the largest THROUGHPUT fraction of the dominant kernel -- valu, hbm,
+lds or l2, achieved rate over that unit's peak -- and `bound` names it, or says "latency" when none exceeds 0.5 (then
+`wait_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES and `lane_util` say where the time goes).  See DESIGN.md section 4:
   valu  useful vector lane-operations (SQ_THREAD_CYCLES_VALU, active lanes only) per second against the chip's issue
         peak for plain f32 vector instructions (tools/micro/valu_peak.hip)           = issue_util x lane_util
   hbm   measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) per second against 8 TB/s
-  td    busy fraction of the texture-data return path (TD_TD_BUSY / elapsed cycles per CU): every divergent 16-byte
-        request of a lane costs it a cycle or more, so scenes whose nodes do not fit the LDS cache run into it
+  lds / l2  bytes the walk requests from the LDS node window / from L1-L2 (device counters of this run) per second
+        against 150 TB/s / 34.5 TB/s
+  td    (diagnostic only, never `frac`) busy fraction of the texture-data return path (TD_TD_BUSY / elapsed cycles per CU)
 The counters are a STORED measurement (profiles/r*_pmc_<workload>.json, written by tools/round_profile.sh with
 rocprofv3 in separate --pmc passes); counts per launch are deterministic for a workload and a build, the launch
 duration is measured live with HIP events.  `algorithmic_GBps` keeps SURVEY 8(d)'s figure (bytes of the REFERENCE's
@@ -330,7 +333,6 @@ def main():
                 td = c["TD_TD_BUSY_sum"] / (256.0 * cyc)
                 roof["td"] = {"busy_frac": round(td, 4), "ta_busy_frac": round(c.get("TA_TA_BUSY_sum", 0.0) / (256.0 * cyc), 4),
                               "vmem_read_wave_insts_per_launch": c.get("SQ_INSTS_VMEM_RD"), "note": "stored ratio (same pass as the counters)"}
-                fracs["td"] = td
             if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
                 roof["lds"] = {"busy_frac": round(c["SQ_LDS_IDX_ACTIVE"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4),
                                "bank_conflict_share": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 4)}
@@ -338,15 +340,27 @@ def main():
                       "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU"):
                 if k in c:
                     roof.setdefault("counters_per_launch", {})[k] = c[k]
+        if pmc:
+            # LDS and L1/L2 request rates of the walk really run (device counters of this run) against their peaks
+            fracs["lds"] = roof["device_requests"]["lds_GBps"] / roof["device_requests"]["lds_peak_GBps"]
+            fracs["l2"] = roof["device_requests"]["l2_GBps"] / roof["device_requests"]["l2_peak_GBps"]
         if fracs:
-            bound = max(fracs, key=fracs.get)     # the limit the kernel is closest to
-            if bound == "valu":
-                roof.update(bound="valu", achieved=roof["valu"]["achieved_Tlaneops"], peak=roof["valu"]["peak_Tlaneops"],
-                            unit="Tlane-op/s", frac=roof["valu"]["frac"])
-            elif bound == "td":
-                roof.update(bound="td", achieved=roof["td"]["busy_frac"], peak=1.0, unit="busy fraction of the texture-data path", frac=roof["td"]["busy_frac"])
-            else:
-                roof.update(bound="hbm", achieved=roof["hbm"]["measured_GBps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=roof["hbm"]["frac"])
+            # `frac` is a THROUGHPUT fraction: the largest of valu / hbm / lds / l2 (achieved rate over that unit's peak).
+            # When none of them exceeds 0.5 no unit is the limit: the kernel waits (dependent node fetches, divergent
+            # lanes) and `bound` says "latency", with the share of wave-cycles spent waiting and the lane utilisation.
+            # td.busy_frac (share of time the texture-data path has work pending) stays a diagnostic, never `frac`.
+            nearest = max(fracs, key=fracs.get)
+            ach = {"valu": lambda: (roof["valu"]["achieved_Tlaneops"], roof["valu"]["peak_Tlaneops"], "Tlane-op/s"),
+                   "hbm": lambda: (roof["hbm"]["measured_GBps"], HBM_PEAK_GBS, "GB/s"),
+                   "lds": lambda: (roof["device_requests"]["lds_GBps"], roof["device_requests"]["lds_peak_GBps"], "GB/s"),
+                   "l2": lambda: (roof["device_requests"]["l2_GBps"], roof["device_requests"]["l2_peak_GBps"], "GB/s")}[nearest]()
+            roof.update(bound=nearest if fracs[nearest] > 0.5 else "latency", nearest_limit=nearest, achieved=ach[0], peak=ach[1], unit=ach[2],
+                        frac=round(fracs[nearest], 4), fracs={k: round(v, 4) for k, v in fracs.items()}, counters="stored")
+            c = pmc["per_launch"]
+            if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+                roof["wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+            if "valu" in roof:
+                roof["lane_util"] = roof["valu"]["lane_util"]
         else:
             # no stored counters for this workload: no fraction is claimed (run tools/round_profile.sh <config>)
             roof.update(bound="unmeasured", achieved=None, peak=None, unit=None, frac=None, traffic=None)
@@ -386,7 +400,10 @@ def cpu_baseline(rt, scene, args):
     frame, sized for 10-30 s of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob  # baseline leg only
-    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    # every core this process may run on, capped at the share the GPU pool allots one box (it exports OMP_NUM_THREADS=16 and
+    # kills runs that oversubscribe; os.cpu_count() there is the whole machine's)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(usable, int(os.environ.get("OMP_NUM_THREADS", str(usable)))))
     w, h, spp = args.width, args.height, min(args.cpu_spp, args.spp)
     if args.config in ("c3", "c3is", "c4"):   # heavier per ray than c2: quarter frame, 4 spp
         w, h, spp = w // 2, h // 2, min(4, spp)
@@ -394,7 +411,7 @@ def cpu_baseline(rt, scene, args):
     t0 = time.perf_counter()
     _, st = ob.render(scene, p, n_threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "cores_visible": usable, "kind": "port",
             "sample": f"same scene at {w}x{h}, {spp} of {args.spp} spp, {st.rays} rays in {dt:.1f} s"}
 
 

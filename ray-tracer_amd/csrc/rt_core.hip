@@ -1122,7 +1122,7 @@ __global__ void rt_debug_kernel(int op, const float* __restrict__ in, size_t n, 
 // file-scope device array, so that the entry point needs no allocation.  Every GPU the library runs on holds its own
 // copy (12 MiB) until the process ends.  In host code the array's NAME is only a stand-in for hipGetSymbolAddress:
 // rt_create looks the address up once per device (noalloc_scratch_of) and everything below uses that pointer.
-#define RT_NOALLOC_MAX_RAYS (1 << 18)
+#define RT_NOALLOC_MAX_RAYS RT_TRACE_NOALLOC_MAX_RAYS  // (the limit include/rt.h states sizes the array)
 #define RT_NOALLOC_CTL_BYTES 256
 #define RT_NOALLOC_BYTES (RT_NOALLOC_CTL_BYTES + (size_t)RT_NOALLOC_MAX_RAYS * (32 + 16))  // queue entry 32 B + hit record 16 B per ray
 static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_BYTES];
@@ -2466,6 +2466,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      reference's i-th light went, and every record carries its reference index (the sum over the lights is formed
     //      in that order, see wave_light_pdf).
     const int nl = s->n_light_tris;
+    if (nl >= (1 << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 - 1 importance-sampled triangles (the light loop packs a light index into 24 bits)");
     const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
     const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 4 * RT_LIGHT_PLANES;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
     const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
@@ -2580,6 +2581,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
 }
 }  // namespace
 
+static int prime_trace_kernels(rt_context* c);
 // The device half of rt_upload_scene: allocations and copies of a layout that is built (rt_comm_upload_scene builds it
 // once for all its ranks).
 static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout& L, UploadTimer& timer) {
@@ -2629,7 +2631,7 @@ static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout&
     c->bvh_depth = L.depth;
     c->short_depth = L.short_depth;
     c->has_scene = true;
-    return RT_OK;
+    return prime_trace_kernels(c);
 }
 
 int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
@@ -2806,6 +2808,15 @@ int set_trace_lds(rt_context* c, const TraceCfg& t) {
     c->trace_lds_set = (int)t.lds_bytes;
     return RT_OK;
 }
+
+}  // namespace
+// The dynamic-LDS attribute of the trace kernels for this scene, set at upload: rt_trace_rays_noalloc then only launches.
+static int prime_trace_kernels(rt_context* c) {
+    int rc = set_trace_lds(c, trace_cfg(c, RT_TRACE_WAVES, false, false));
+    if (rc == RT_OK && c->sc.short_root != RT_TRAV_DONE) rc = set_trace_lds(c, trace_cfg(c, RT_TRACE_WAVES, false, true));
+    return rc;
+}
+namespace {
 
 typedef void (*paths_fn)(Scene, Params, float*, unsigned int*, unsigned long long*, int, int, int, int, unsigned int, int);
 paths_fn paths_kernel_variant(bool stats, bool big, bool extra, bool coop, bool tlds = false, bool fast = false) {

@@ -68,8 +68,8 @@ namespace rtd {
 // leaf visit and all the leaf's triangle tests, like the walk it replaces.
 // tri cold   (64 B = 4 x float4): n0 n1 n2 (9), uv0 uv1 uv2 (6), matId bits (1)
 // material   (48 B = 3 x float4): (type bits, r, g, b) (p1, p2, p3, off0 bits) (off1, off2, w, h bits)
-// light      (80 B = 5 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) reference index (int bits); stored plane by plane
-//            per group of RT_LIGHT_GROUP lights (RT_LIGHT_F4 below)
+// light      (96 B = 6 x float4): p1(3) e1(3) e2(3) normal(3) area(1) p2(3) p3(3) reference index (int bits), then (centre, padded radius) of
+//            the triangle's bounding sphere; stored plane by plane per group of RT_LIGHT_GROUP lights (RT_LIGHT_F4 below)
 // light box  (32 B = 2 x float4): padded bounds (min, 0) (max, 0) of lights [16 g, 16 g + 16), behind the light records
 // sphere     (32 B = 2 x float4): (cx, cy, cz, r) (matId bits, 0, 0, 0)
 struct Scene {
@@ -121,7 +121,7 @@ struct Params {
 };
 
 // Light records are stored plane by plane per group of RT_LIGHT_GROUP lights: float4 p of light j stands at
-// ((j / G) * 5 + p) * G + j % G, so that the G lanes of a slot which test the G lights of a group (wave_light_pdf) read
+// ((j / G) * RT_LIGHT_PLANES + p) * G + j % G, so that the G lanes of a slot which test the G lights of a group (wave_light_pdf) read
 // 16 G contiguous bytes per request instead of 16 bytes every 80 (the texture path serves a request in proportion to
 // the lines it touches: it was the limit of the light loop).
 #ifndef RT_LIGHT_GROUP
@@ -1262,9 +1262,12 @@ __device__ __forceinline__ float wave_light_pdf_q(const Scene& sc, const LightQu
                     const float4 sp = sc.lights[((size_t)(base / RT_LIGHT_GROUP + gs) * RT_LIGHT_PLANES + 5) * RT_LIGHT_GROUP + sub];
                     const f3 v = mk(sp.x, sp.y, sp.z) - hp;
                     const float b = dot(v, og), v2 = len2(v), r2 = sp.w * sp.w;
-                    // squared distance of the centre from the ray's LINE, times |og|^2, against the radius; 4e-7 v2: the rounding of
-                    // v2 og2 - b^2 itself.  Behind the origin (b < 0) only a sphere that holds the origin can be hit.
-                    pass = far || ((v2 * og2 - b * b <= r2 * og2 + 4e-7f * v2 * og2) && (b >= 0.0f || v2 <= r2));
+                    // squared distance of the centre from the ray's LINE, times |og|^2, against the radius.  The slack covers the
+                    // rounding of v2 og2 - b^2 itself: v2 and og2 are off by 1.8e-7 each and their product by 6e-8 more, b by
+                    // 1.8e-7 |v| |og| and so b^2 by 3.6e-7 v2 og2 -- 8.4e-7 v2 og2 at worst, which for a small light hundreds of
+                    // radii away is more than the radius' 0.1 % of padding.  Behind the origin (b < 0) only a sphere that holds
+                    // the origin can be hit.
+                    pass = far || ((v2 * og2 - b * b <= r2 * og2 + 2e-6f * v2 * og2) && (b >= 0.0f || v2 <= r2 * 1.000001f));
                 }
                 const unsigned long long pm = __ballot(pass);
                 if (pm) {

@@ -235,6 +235,40 @@ def test_light_sum_with_many_nonzero_terms_keeps_the_reference_order(ob, rt, gpu
         assert st.dev_light_tests != st.light_tests                  # the wave-cooperative loop ran (and the ordered re-sum on top of it)
 
 
+@pytest.mark.parametrize("size,dist", [(2e-3, 4.0), (3e-4, 9.0)])
+def test_tiny_lights_thousands_of_radii_away_are_not_culled(ob, rt, gpu, size, dist):
+    """The two-phase light loop drops a light whose padded bounding sphere the query's ray misses; the test forms
+    |v|^2 |d|^2 - (v.d)^2, which cancels almost completely for a small light far away.  96 light triangles of 2 mm / 0.3 mm,
+    2 000 / 30 000 radii from the type-5 floor that samples them: every sampled direction passes through one of them, and
+    its pdf term must not be lost (sums and light-test counts equal to the oracle's plain loop over every light)."""
+    rng = np.random.default_rng(11)
+    recs = []
+    def tri(a, b, c, mat, light=False):
+        r = np.zeros(25, np.float32)
+        r[0:9] = np.concatenate([a, b, c]); n = np.cross(np.subtract(b, a), np.subtract(c, a)); n = n / np.linalg.norm(n)
+        r[9:18] = np.tile(n, 3); r[24] = (1000 if light else 0) + mat + 0.001
+        return r
+    recs.append(tri([-6, -1, 2], [6, -1, 2], [6, -1, -10], 0)); recs.append(tri([-6, -1, 2], [6, -1, -10], [-6, -1, -10], 0))
+    for k in range(96):
+        c = np.array([rng.uniform(-3, 3), -1 + dist + rng.uniform(0, 1), rng.uniform(-8, 0)])
+        a, b = rng.normal(0, 1, 3), rng.normal(0, 1, 3)
+        a[1] *= 0.2; b[1] *= 0.2                                       # mostly facing down
+        recs.append(tri(c, c + size * a, c + size * b, 1, light=True))
+    floor = rt.Material(); floor.type = 5; floor.color = 0xC0C0C0; floor.image_offset[:] = [-1, -1, -1]
+    glow = rt.Material(); glow.type = 1; glow.color = 0xFFFFFF; glow.p1 = 50.0; glow.image_offset[:] = [-1, -1, -1]
+    sc = rt.Scene.from_records(np.stack(recs), [floor, glow])
+    assert sc.desc.n_light_tris == 96
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=16, width=64, height=48, max_bounces=3, flags=rt.F_DEFAULT | rt.F_STATS)
+    p.cam.pos[:] = [0, 0.1, 1.5]; p.cam.rot[:] = [-0.35, 0, 0]
+    gpu.reset(); st = gpu.render(p); img = gpu.readback()
+    o, ost = ob.render(sc, p, n_threads=8)
+    assert ost.light_tests > 96 * 10000 and ost.hits > ost.paths         # the floor queries the lights, and sampled rays reach them
+    assert np.array_equal(img, o)
+    assert (st.rays, st.hits, st.light_tests) == (ost.rays, ost.hits, ost.light_tests)
+    assert st.dev_light_tests < st.light_tests // 8                      # (the culling did run)
+
+
 def image_metrics(a, b):
     ya, yb = a @ LUMA, b @ LUMA
     mean_rel = abs(float(ya.mean()) - float(yb.mean())) / float(yb.mean())
