@@ -295,7 +295,7 @@ def main():
         roof["device_requests"] = {
             "walk": args.walk if args.mode == "megakernel" else "reference",
             "inner_items_visited": int(st_dev.dev_inner_visits), "of_those_from_lds": int(st_dev.dev_lds_inner_visits),
-            "triangle_tests_run": int(st_dev.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
+            "wide_visits": int(st_dev.dev_wide_visits), "triangle_tests_run": int(st_dev.dev_tri_tests), "reference_walk_triangle_tests": int(st_counts.tri_tests),
             "reference_walk_inner_visits": int(st_counts.inner_visits), "shortcut_rewalks": int(st_dev.shortcut_rewalks),
             "scene_has_shortcut_tree": bool(st_dev.dev_inner_visits != st_counts.dev_inner_visits or st_dev.shortcut_rewalks),
             "light_tests_run": int(st_dev.dev_light_tests), "reference_walk_light_tests": int(st_counts.light_tests),

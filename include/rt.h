@@ -196,6 +196,9 @@ typedef struct rt_render_stats {
     uint64_t dev_tri_tests;        /* triangle tests really run, 48 B each */
     uint64_t dev_light_tests;      /* light-triangle pdf tests really run (after the culling of light groups), 64 B each */
     uint64_t shortcut_rewalks;     /* searches whose shortcut-tree result was not certified and that walked the reference's tree again */
+    /* round 3 */
+    uint64_t dev_wide_visits;      /* visits of wide (four-child) shortcut nodes: 128 B each, counted as TWO items in dev_inner_visits /
+                                      dev_lds_inner_visits */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };
@@ -346,6 +349,11 @@ typedef struct rt_layout_info {
     int32_t short_depth; /* traversal stack entries of the shortcut walk */
     int32_t short_single; /* the shortcut tree stands over single triangles (scenes too small for sub-trees) */
     int32_t short_cut;    /* huge scenes: levels below the reference's leaves at which the shortcut tree's leaves stand */
+    /* round 3 */
+    int32_t n_wide;       /* the shortcut tree's nodes have up to FOUR children and take two items each, items [short_base,
+                             short_base + 2 n_wide) (layout in csrc/rt_device.h); 0 = two-child shortcut nodes; n_short == n_wide then */
+    int32_t wide_need;    /* stack entries the worst path of the wide tree needs */
+    int32_t wide_sp_max;  /* a wide visit with more entries than this on the stack gives up (the ray walks the reference's tree) */
 } rt_layout_info;
 int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
 int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places); /* round 1's symbol: fills RT_LAYOUT_INFO_V1_SIZE bytes */

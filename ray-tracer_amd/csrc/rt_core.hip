@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_REF_FRONT 1024        // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
+#define RT_WIDE_STACK 15         // stack entries a search of the WIDE shortcut tree may use for itself (a deeper path gives up and walks the reference's tree)
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
 #define RT_SHORT_FRONT_MAX (1 << 18)  // ... with at most this many entries (the 10M-triangle field, 4 spp frames: leaves 15.56 ms, 2 levels below them --
                                       // 262 k entries, 25 ms of build -- 14.43, 4 levels -- 1 M, 96 ms -- 14.43, 6 levels 14.49, runs -- 6.2 M, 0.5 s -- 13.8 to 14.5)
@@ -246,6 +247,12 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #endif
 #ifndef RT_INNER_ROLLED
 #define RT_INNER_ROLLED 0
+#endif
+#ifndef RT_WIDE_STEPS
+#define RT_WIDE_STEPS 2         // visits of wide (four-child) shortcut nodes per vote
+#endif
+#ifndef RT_WIDE_STEPS_TINY
+#define RT_WIDE_STEPS_TINY 3    // ... in a scene that sits in the LDS entirely
 #endif
 #ifndef RT_INNER_STEPS_TINY
 #define RT_INNER_STEPS_TINY 6   // ... on the shortcut walk of a scene that sits in the LDS entirely (the Cornell box, 256 spp: 4 / 5 / 6 / 7 / 8 / 12 = 109.1 / 109.0 / 97.3 / 98.4 / 98.8 / 99.8 ms at a vertex vote of 48)
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         const bool at_inner = trav_at_inner(sc, t);
         const bool at_leaf = t.cur >= sc.n_inner;  // a triangle or RT_TRAV_EMPTY
         const unsigned long long mLeaf = __ballot(at_leaf);
-#ifdef RT_CYCLE_PROF
+#if defined(RT_CYCLE_PROF) && RT_CYCLE_PROF != 2
         {   // lane census of this iteration: who steps, who waits for what
             const bool leaf_iter = __popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0;
             const int base = leaf_iter ? 12 : 8;
@@ -527,9 +534,11 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         }
 #endif
         if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
+            RT_PROF_COUNT(cn, 13, 1);
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
+                RT_PROF_LANE(cn, 14);
                 trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
 #pragma unroll
                 for (int k = 1; k < RT_LEAF_STEPS; k++)
@@ -538,19 +547,42 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 // over leaves with their sub-trees, the 10M-triangle field, it loses 1 %)
                 if (FAST && RT_LEAF_STEPS == 1 && sc.short_runs && t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
             }
+#if RT_CYCLE_PROF == 2
+            RT_PROF_COUNT(cn, 10, RT_PROF_CLOCK() - pt0);
+#endif
         } else {
-            if (at_inner) {
+            // wide shortcut nodes (rt_device.h) and two-child nodes (the reference's on a re-walk, sub-tree nodes below the
+            // shortcut tree) are visited by separate code, each run only if some lane of the wave stands at such a node
+            const bool at_wide = FAST && at_inner && trav_at_wide(sc, t);
+            if (FAST && __ballot(at_wide)) {
+                RT_PROF_COUNT(cn, 11, 1);
+                if (at_wide) {
+                    RT_PROF_COUNT(cn, 0, 1);
+                    RT_PROF_LANE(cn, 1);
+                    RT_PROF_LANE(cn, 15);
+                    trav_step_wide<STATS, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+#pragma unroll
+                    for (int k = 1; k < (TLDS ? RT_WIDE_STEPS_TINY : RT_WIDE_STEPS); k++)
+                        if (trav_at_wide(sc, t)) trav_step_wide<STATS, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                }
+            }
+#if RT_CYCLE_PROF == 2
+            [[maybe_unused]] const unsigned long long pt1 = RT_PROF_CLOCK();
+            RT_PROF_COUNT(cn, 8, pt1 - pt0);
+            if (__ballot(at_inner && !at_wide)) RT_PROF_COUNT(cn, 12, 1);
+#endif
+            if (at_inner && !at_wide && (!FAST || trav_at_inner(sc, t))) {
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
 #if RT_INNER_ROLLED  // (experiments: ONE copy of the visit's code in a counted loop)
 #pragma unroll 1
                 for (int k = 0; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)
-                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #else
                 trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
                 for (int k = 1; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
-                    if (trav_at_inner(sc, t)) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
 #endif
             }
         }
@@ -565,11 +597,19 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     }
 
     RT_PROF_COUNT(cn, 6, RT_PROF_CLOCK() - plife0);
+#if RT_CYCLE_PROF == 2
+    if (!STATS)
+        for (int i = 0; i < 16; i++) {
+            unsigned long long s = cn.prof[i];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0 && s) atomicAdd(&stats[16 + i], s);
+        }
+#endif
     if (STATS) {
-        uint32_t v[13] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights,
-                          cn.rewalks};
+        uint32_t v[14] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights,
+                          cn.rewalks, cn.dev_wide};
 #pragma unroll
-        for (int i = 0; i < 13; i++) {
+        for (int i = 0; i < 14; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
@@ -1418,6 +1458,7 @@ struct HostLayout {
     bool short_runs = false, short_single = false;
     int short_cut = 0;
     int n_short = 0, short_root = RT_TRAV_DONE, short_base = 0, short_depth = 0;  // shortcut tree (rt_device.h): nodes, root item, first item of its LDS window, stack entries
+    int n_wide = 0, wide_need = 0, below_short = 0;  // wide (four-child) shortcut nodes, two items each from short_base on; stack entries their worst path needs; levels of sub-trees below the shortcut tree
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
 };
@@ -2244,15 +2285,63 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             short_levels = deepest_short.load();
         }
     }
+    // ---- WIDE SHORTCUT NODES (rt_device.h): the binary tree collapsed into nodes of up to four children -- the child with
+    //      the biggest box is replaced by its own two children until there are four (or only leaves are left).  The
+    //      binary nodes are then not emitted.  RT_SHORT_BINARY keeps them (experiments, tests of the two-child form).
+    struct WideNode { float box[4][6]; int e[4]; int nk; };  // e >= 0: wide node; e < 0: ~(ShortPrim::node of what hangs there); slots >= nk unused
+    std::vector<WideNode> wides;
+    int wide_root = -1, wide_need = 0;  // (stack entries a search of the wide tree can need: sum of (children - 1) down the worst path)
+    if (short_root >= 0 && !getenv("RT_SHORT_BINARY")) {
+        wides.reserve(shorts.size() / 2 + 1);
+        auto collapse = [&](auto&& self, int bnode, int& need) -> int {
+            const float* kbox[4];
+            int ke[4], nk = 2;
+            kbox[0] = shorts[(size_t)bnode].box[0]; ke[0] = shorts[(size_t)bnode].e[0];
+            kbox[1] = shorts[(size_t)bnode].box[1]; ke[1] = shorts[(size_t)bnode].e[1];
+            while (nk < 4) {
+                int best = -1;
+                float ba = -1.f;
+                for (int i = 0; i < nk; i++)
+                    if (ke[i] >= 0 && half_area(kbox[i]) > ba) { ba = half_area(kbox[i]); best = i; }
+                if (best < 0) break;
+                const ShortNode& c = shorts[(size_t)ke[best]];
+                kbox[best] = c.box[0]; ke[best] = c.e[0];
+                kbox[nk] = c.box[1]; ke[nk] = c.e[1];
+                nk++;
+            }
+            const int idx = (int)wides.size();
+            wides.push_back(WideNode());
+            WideNode nd;
+            nd.nk = nk;
+            int below = 0;
+            for (int i = 0; i < 4; i++) {
+                if (i < nk) {
+                    memcpy(nd.box[i], kbox[i], 6 * sizeof(float));
+                    int nb = 0;
+                    nd.e[i] = ke[i] >= 0 ? self(self, ke[i], nb) : ke[i];
+                    below = std::max(below, nb);
+                } else {
+                    for (int k = 0; k < 6; k++) nd.box[i][k] = 3e38f;  // min = max far outside: no ray reaches it (rt_device.h)
+                    nd.e[i] = 0;
+                }
+            }
+            wides[(size_t)idx] = nd;
+            need = nk - 1 + below;
+            return idx;
+        };
+        wide_root = collapse(collapse, short_root, wide_need);
+        shorts.clear();
+    }
+    const int n_wide = (int)wides.size();
     const int n_short = (int)shorts.size();
     timer.stage("shortcut tree");
-    n_inner = n_top + n_sub + n_short;
+    n_inner = n_top + n_sub + n_short + 2 * n_wide;
     // Item index of every inner node, the reference's and the sub-trees' alike.  The RT_ITEM_FRONT nodes with the biggest
     // boxes come first, biggest first (ties: the reference's nodes in their order, then the sub-tree nodes in theirs): a
     // random ray meets a box in proportion to its area, and the LDS node cache of the kernels holds the items from the
     // front.  Behind them the reference's BFS order and the sub-trees' depth-first order stay as they are, which keeps
     // neighbours in the tree close in memory.  "Node q" below: q < nn is the reference's node q, q >= nn sub-tree node q - nn.
-    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0), short_index((size_t)std::max(n_short, 1), 0);
+    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0), short_index((size_t)std::max(n_short, 1), 0), wide_index;
     int short_base = 0;
     {
         struct Key { float area; int kind, id; };
@@ -2317,7 +2406,31 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         // RT_REF_FRONT of its own biggest nodes, then the window below --, the shortcut walk items [short_base, short_base +
         // n_cached): the biggest shortcut nodes (and sub-tree nodes, where it enters sub-trees), which is all it visits.
         std::vector<Key> big;
-        if (n_short > 0 && front) {
+        size_t rest_base = 0;  // first item index of the nodes that are not in `big`
+        if (n_wide > 0) {
+            // [0, short_base): the reference's biggest nodes (its walk's window starts there); [short_base, short_base + 2 n_wide): the
+            // wide nodes, ONE index range (trav_at_wide), the `front` biggest first by box area (the shortcut walk's window is the
+            // head of that range), the others in tree order; then every other reference node and the sub-tree nodes
+            big = select(1, front ? std::min<size_t>(RT_REF_FRONT, (size_t)n_top) : 0);
+            short_base = (int)big.size();
+            std::vector<std::pair<float, int>> wk((size_t)n_wide);
+            for (int w = 0; w < n_wide; w++) {
+                float u[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+                for (int i = 0; i < wides[(size_t)w].nk; i++)
+                    for (int c = 0; c < 3; c++) {
+                        u[c] = std::min(u[c], wides[(size_t)w].box[i][c]);
+                        u[3 + c] = std::max(u[3 + c], wides[(size_t)w].box[i][3 + c]);
+                    }
+                wk[(size_t)w] = {w == wide_root ? 3e38f : half_area(u), w};
+            }
+            const size_t nf = std::min<size_t>(front, (size_t)n_wide);
+            auto wbigger = [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; };
+            std::partial_sort(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wk.end(), wbigger);
+            std::sort(wk.begin() + (std::ptrdiff_t)nf, wk.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.second < b.second; });
+            wide_index.assign((size_t)n_wide, 0);
+            for (int k = 0; k < n_wide; k++) wide_index[(size_t)wk[(size_t)k].second] = short_base + 2 * k;
+            rest_base = (size_t)short_base + 2 * (size_t)n_wide;
+        } else if (n_short > 0 && front) {
             big = select(1, std::min<size_t>(RT_REF_FRONT, (size_t)n_top));
             short_base = (int)big.size();
             const std::vector<Key> rest = select(short_runs ? 4 : 2 | 4, front);  // (over runs the shortcut walk never enters a sub-tree)
@@ -2325,6 +2438,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         } else {
             big = select(1 | 2 | 4, front);
         }
+        if (n_wide == 0) rest_base = big.size();
         std::vector<char> taken(std::max<size_t>(nq, 1), 0);
         for (size_t k = 0; k < big.size(); k++) {
             const Key& b = big[k];
@@ -2341,7 +2455,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         });
         for (int wi = 0; wi < nr; wi++) cnt[(size_t)wi + 1] += cnt[(size_t)wi];
         par_ranges(nq, [&](int wi, size_t lo, size_t hi) {
-            size_t k = big.size() + cnt[(size_t)wi];
+            size_t k = rest_base + cnt[(size_t)wi];
             for (size_t q = lo; q < hi; q++) {
                 if (taken[q]) continue;
                 if (q < (size_t)nn) {
@@ -2432,6 +2546,22 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 w[12 + k] = i2f(nd.e[k] >= 0 ? short_index[(size_t)nd.e[k]] : ((~nd.e[k] & 1) ? sub_index[(size_t)(~nd.e[k] >> 1)] : n_inner + (~nd.e[k] >> 1)));
             w[14] = i2f(0);
             w[15] = i2f(2);
+        }
+    });
+    par_ranges((size_t)n_wide, [&](int, size_t lo, size_t hi) {  // wide shortcut nodes: two items each (layout in rt_device.h)
+        for (size_t j = lo; j < hi; j++) {
+            const WideNode& nd = wides[j];
+            float* w = &items[(size_t)wide_index[j] * 16];
+            for (int i = 0; i < 4; i++) {
+                for (int c = 0; c < 3; c++) {
+                    w[4 * c + i] = nd.box[i][c];            // item 0: min.x[4], min.y[4], min.z[4]
+                    w[16 + 4 * c + i] = nd.box[i][3 + c];   // item 1: max.x[4], max.y[4], max.z[4]
+                }
+                int e = RT_TRAV_EMPTY;
+                if (i < nd.nk) e = nd.e[i] >= 0 ? wide_index[(size_t)nd.e[i]] : ((~nd.e[i] & 1) ? sub_index[(size_t)(~nd.e[i] >> 1)] : n_inner + (~nd.e[i] >> 1));
+                w[12 + i] = i2f(e);
+            }
+            w[28] = i2f(nd.nk); w[29] = i2f(0); w[30] = i2f(0); w[31] = i2f(3);
         }
     });
     L.ref_boxes.assign((size_t)std::max(nn, 1) * 8, 0.f);
@@ -2565,13 +2695,21 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.n_sub = n_sub;
     L.n_tris = ntri;
     L.depth = deepest;
-    L.n_short = n_short;
-    L.short_root = short_root >= 0 ? short_index[(size_t)short_root] : RT_TRAV_DONE;
+    L.n_short = n_wide > 0 ? n_wide : n_short;
+    L.n_wide = n_wide;
+    L.short_root = wide_root >= 0 ? wide_index[(size_t)wide_root] : (short_root >= 0 ? short_index[(size_t)short_root] : RT_TRAV_DONE);
+    L.wide_need = wide_need;
+    L.below_short = below_leaf;
     L.short_base = short_base;
     L.short_runs = short_runs;
     L.short_single = short_single;
     L.short_cut = short_cut;
-    L.short_depth = n_short > 0 ? short_levels + below_leaf : 0;
+    // stack entries of a shortcut search.  The wide tree's worst path may need many (three per level); the search is given
+    // RT_WIDE_STACK of them and gives up beyond (trav_step_wide: the ray then walks the reference's tree)
+    // (+ 2: a visit wants room for three pushes even where the node has two children)
+    int wide_stack = RT_WIDE_STACK;
+    if (const char* e = getenv("RT_WIDE_STACK")) wide_stack = std::max(5, atoi(e));  // experiments only
+    L.short_depth = n_wide > 0 ? std::min(wide_need + 2, wide_stack) + below_leaf : (n_short > 0 ? short_levels + below_leaf : 0);
     L.light_box_off = light_box_off;
     L.light_place_off = light_place_off;
     L.scene_scale = scene_scale;
@@ -2606,6 +2744,10 @@ static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout&
     sc.short_base = L.short_base;
     sc.short_runs = L.short_runs ? 1 : 0;
     sc.short_single = L.short_single ? 1 : 0;
+    sc.wide_lo = L.short_base;
+    sc.wide_n = 2 * L.n_wide;
+    // (the stack has max(depth, short_depth) entries: trace_cfg; the sub-trees below the shortcut tree push one entry per level)
+    sc.wide_sp_max = std::max(L.depth, L.short_depth) - L.below_short - 3;
     sc.n_inner = L.n_inner;
     sc.n_sub = L.n_sub;
     sc.cull_far = RT_CULL_FAR * L.scene_scale;
@@ -2684,6 +2826,9 @@ int rt_layout_get_v2(const rt_layout* h, rt_layout_info* info_out, size_t info_s
         info->short_depth = h->L.short_depth;
         info->short_single = h->L.short_single ? 1 : 0;
         info->short_cut = h->L.short_cut;
+        info->n_wide = h->L.n_wide;
+        info->wide_need = h->L.wide_need;
+        info->wide_sp_max = std::max(h->L.depth, h->L.short_depth) - h->L.below_short - 3;
         memcpy(info_out, &full, std::min(info_size, sizeof(full)));
     }
     if (items) *items = h->L.items.data();
@@ -3111,7 +3256,11 @@ int render_impl(rt_context* c, const rt_render_params* p, rt_render_stats* stats
     const bool want_stats = (P.flags & RT_F_STATS) != 0;
     const bool profile = (P.flags & RT_F_PROFILE) != 0;
     if (stats) memset(stats, 0, sizeof(*stats));
+#if RT_CYCLE_PROF == 2
+    if (true) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 32 * sizeof(unsigned long long), c->stream));
+#else
     if (want_stats) HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, 32 * sizeof(unsigned long long), c->stream));
+#endif
     const bool work = P.n_tiles > 0 && P.sample_count > 0;
     if (work) {
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -3128,6 +3277,18 @@ int render_impl(rt_context* c, const rt_render_params* p, rt_render_stats* stats
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
             stats->kernel_ms = ms;
         }
+#if RT_CYCLE_PROF == 2
+        if (!want_stats && work) {  // the clocks of the kernel without counters: where a wave's cycles go
+            unsigned long long h[32];
+            HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+            const double life = (double)std::max<unsigned long long>(h[22], 1);
+            fprintf(stderr, "[rt prof2] kernel %.3f ms; wave lifetime split: traversal %.3f (wide part %.3f, two-child part %.3f, leaf iterations %.3f), vertex passes %.3f (shading part %.3f); "
+                            "iterations: wide %llu (%.1f lanes), two-child %llu, leaf %llu (%.1f lanes); vertex passes %llu (%.1f lanes); cycles per wide iteration %.0f, per leaf iteration %.0f, per vertex pass %.0f\n",
+                    stats->kernel_ms, h[18] / life, h[24] / life, (h[18] - h[24] - h[26]) / life, h[26] / life, h[21] / life, h[23] / life,
+                    h[27], h[27] ? (double)h[31] / h[27] : 0.0, h[28], h[29], h[29] ? (double)h[30] / h[29] : 0.0, h[19], h[19] ? (double)h[20] / h[19] : 0.0,
+                    h[27] ? (double)h[24] / h[27] : 0.0, h[29] ? (double)h[26] / h[29] : 0.0, h[19] ? (double)h[21] / h[19] : 0.0);
+        }
+#endif
         if (want_stats) {
             unsigned long long h[32];
             HIP_TRY(c, hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
@@ -3151,7 +3312,7 @@ int render_impl(rt_context* c, const rt_render_params* p, rt_render_stats* stats
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
-            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11]; stats->shortcut_rewalks = h[12];
+            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11]; stats->shortcut_rewalks = h[12]; stats->dev_wide_visits = h[13];
         }
     }
     return RT_OK;

@@ -58,6 +58,17 @@ namespace rtd {
 // the other up to a 'last' flag); in a scene with more than 2^20 runs what stands a few levels below each reference leaf
 // in its sub-tree (the walk then continues into the sub-tree); in a scene too small for sub-trees its SINGLE triangles
 // (short_single: a shortcut search leaves a leaf after one test, whatever the 'last' flags say).
+// WIDE SHORTCUT NODES (round 3).  The shortcut tree is this library's own, so its arity is free too: the binary tree the
+// surface-area builder makes is collapsed into nodes of up to FOUR children (the child with the biggest box is replaced by
+// its own two children until there are four), stored as TWO consecutive items = 128 bytes:
+//     item 0: q0 = min.x of children 0..3, q1 = min.y, q2 = min.z, q3 = entries 0..3 (int bits)
+//     item 1: q0 = max.x,                  q1 = max.y, q2 = max.z, q3 = (children, 0, 0, 3) (int bits; not read by the kernels)
+// A missing child has the box min = max = 3e38 (no ray reaches it) and the entry RT_TRAV_EMPTY.  A visit tests the four
+// boxes in one go -- half as many dependent node fetches per ray, four independent slab tests per lane to overlap -- with
+// t = fma(bound, 1/d, -o/d) (one instruction per plane; off by 6e-8 (|o| + |bound|) in space, well inside the boxes'
+// padding, and a shortcut search only has to be CONSERVATIVE: the certificate restores exactness), sorts the children
+// that are hit by entry distance, pushes up to three and goes on with the nearest.  Wide nodes stand in ONE index range,
+// [wide_lo, wide_lo + wide_n), biggest boxes first: that range's head is the LDS window of the shortcut walk.
 // LEAF SUB-TREES.  The reference tests EVERY triangle of a leaf, in array order, and a later triangle replaces the
 // hit only if strictly closer (main.cu:249-264): the leaf's result is the closest hit below the distance the ray
 // arrived with and, among equals, the one first in the array -- which does not depend on the order of the tests, and
@@ -80,6 +91,9 @@ struct Scene {
     int short_base;          // first item of the window [short_base, short_base + n_cached) the shortcut walk caches in LDS
     int short_single;        // ... over single triangles (tiny scenes): a shortcut search leaves a leaf after ONE test, whatever its 'last' flag
     int short_runs;          // the shortcut tree stands over the runs of the item stream (short ones: two triangle tests per leaf iteration pay)
+    int wide_lo, wide_n;     // WIDE shortcut nodes (four children, two items each): items [wide_lo, wide_lo + wide_n); wide_n = 0: binary shortcut nodes
+    int wide_sp_max;         // a wide visit needs room for three pushes (and the sub-trees below the shortcut tree for theirs): with more than this
+                             // many entries on its stack the search gives up and the ray walks the reference's tree
     const float4* tri_cold;
     const float4* mats;
     const float4* lights;
@@ -176,12 +190,21 @@ __device__ __forceinline__ f3 lerp3(f3 a, f3 b, float t) {  // vec3.h:125-131
 __device__ __forceinline__ f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 // ------------------------------------------------------------------ counter RNG (rt.h)
+#ifndef RT_PHILOX_MAD64
+#define RT_PHILOX_MAD64 1
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
+#if RT_PHILOX_MAD64
+        // both halves of a product from ONE v_mad_u64_u32 (32-bit integer multiplies issue at a quarter of the rate: 40 of them per block otherwise)
+        const unsigned long long p0 = (unsigned long long)c0 * 0xD2511F53u, p1 = (unsigned long long)c2 * 0xCD9E8D57u;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -216,12 +239,13 @@ struct Counters {
     // inner items visited (reference nodes and sub-tree nodes), of those served by the LDS node cache, triangle tests run
     uint32_t rewalks;  // shortcut searches that were not certified and walked the reference's tree again
     uint32_t dev_inner, dev_cached, dev_tri, dev_lights;  // (dev_lights: light-triangle pdf tests really run, after the group culling)
+    uint32_t dev_wide;  // visits of wide shortcut nodes (each also counts two items in dev_inner / dev_cached)
 #ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
     unsigned long long prof[16];  // (8..15: lane census per iteration kind, rt_render_paths_kernel)   0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
 #endif
     __device__ __forceinline__ void clear() {
         paths = rays = inner = leaf = tri = hits = texels = lights = 0;
-        dev_inner = dev_cached = dev_tri = dev_lights = rewalks = 0;
+        dev_inner = dev_cached = dev_tri = dev_lights = rewalks = dev_wide = 0;
 #ifdef RT_CYCLE_PROF
         for (int i = 0; i < 16; i++) prof[i] = 0;
 #endif
@@ -229,10 +253,18 @@ struct Counters {
 };
 #ifdef RT_CYCLE_PROF
 __device__ __forceinline__ bool prof_leader() { return (threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1; }
-#define RT_PROF_COUNT(cn, i, v) do { if (STATS && prof_leader()) (cn).prof[i] += (v); } while (0)
-#define RT_PROF_LANE(cn, i) do { if (STATS) (cn).prof[i] += 1; } while (0)
-#define RT_PROF_CLOCK() (STATS ? (unsigned long long)clock64() : 0ull)
+// -DRT_CYCLE_PROF=2: the clocks alone, in the kernel WITHOUT counters (the counters of RT_F_STATS slow the traversal down by
+// a factor of two and more, which distorts the split); the lane census is left out then
+#if RT_CYCLE_PROF == 2
+#define RT_PROF_ON true
 #else
+#define RT_PROF_ON STATS
+#endif
+#define RT_PROF_COUNT(cn, i, v) do { if (RT_PROF_ON && prof_leader()) (cn).prof[i] += (v); } while (0)
+#define RT_PROF_LANE(cn, i) do { if (RT_PROF_ON) (cn).prof[i] += 1; } while (0)
+#define RT_PROF_CLOCK() (RT_PROF_ON ? (unsigned long long)clock64() : 0ull)
+#else
+#define RT_PROF_ON false
 #define RT_PROF_COUNT(cn, i, v) do {} while (0)
 #define RT_PROF_LANE(cn, i) do {} while (0)
 #define RT_PROF_CLOCK() 0ull
@@ -400,7 +432,14 @@ struct Trav {
     float slack;  // sub-tree pruning: bound on the rounding error of a squared distance from this origin
     float subLim; // minD2 with that slack: what a sub-tree node's squared distance is compared with
     float invD2;  // 1 / |d|^2, a little up: the reference compares t^2 of a box with |d t|^2 of a hit (equal for unit directions)
-    __device__ __forceinline__ void set_min(float m) { minD2 = m; subLim = (m * 1.00002f + slack) * invD2; }
+    int sgx, sgy, sgz;  // wide shortcut nodes: 80 (bytes from a node's min.x piece to its max.x piece in the LDS window; & 64 = the same in device
+                        // memory) where the ray runs DOWN that axis, else 0: a visit then fetches the near and far planes themselves
+    float limT;   // wide shortcut nodes: sqrt(subLim), a little up -- what a child box's entry PARAMETER is compared with
+    __device__ __forceinline__ void set_min(float m) {
+        minD2 = m;
+        subLim = (m * 1.00002f + slack) * invD2;
+        limT = __builtin_amdgcn_sqrtf(subLim) * 1.00001f;  // (v_sqrt_f32, 1 ulp: the factor covers it; only ever makes the walk visit more)
+    }
     float minD2;  // minDistSqr, main.cu:223
     float rival;  // shortcut walk: smallest squared distance of a hit in another reference leaf than the best one's; < 0 = this search walks the reference's tree
     int bestLeaf; // shortcut walk: leafEnd of the best hit (names its reference leaf), -1 before the first hit
@@ -601,6 +640,10 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
     else t.cur++;
 }
 
+__device__ __forceinline__ bool trav_at_wide(const Scene& sc, const Trav& t);
+template <bool STATS, bool ALL_CACHED = false>
+__device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached, int cache_base);
+
 // ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit or one
 // triangle test of the current leaf.  All lanes of the wave share the four item loads, whatever kind
 // of item each of them holds.
@@ -609,6 +652,10 @@ __device__ __forceinline__ void trav_step(const Scene& sc, Trav& t, int* stk, Co
     if (t.cur == RT_TRAV_EMPTY) {  // empty leaf: counted as a visit, nothing to test
         if (STATS) cn.leaf++;
         trav_pop(t, stk);
+        return;
+    }
+    if (FAST && trav_at_wide(sc, t)) {
+        trav_step_wide<STATS>(sc, t, stk, cn, n_cached, cache_base);
         return;
     }
     float4 q0, q1, q2, q3;
@@ -644,6 +691,93 @@ __device__ __forceinline__ void trav_step_inner(const Scene& sc, Trav& t, int* s
     visit_inner<STATS, SUB>(t, stk, cn, q0, q1, q2, q3);
 }
 
+// ---- wide shortcut nodes (see WIDE SHORTCUT NODES above)
+#ifndef RT_WIDE_SORT
+#define RT_WIDE_SORT 1  // 1 = the children that are hit go on the stack in order of their entry distance (five compare-exchanges);
+#endif                  // 0 = only the nearest is picked out, the others are pushed as they come (fewer instructions, a few more visits)
+__device__ __forceinline__ bool trav_at_wide(const Scene& sc, const Trav& t) { return (unsigned)(t.cur - sc.wide_lo) < (unsigned)sc.wide_n; }
+
+// entry parameter of one child box, +inf when the ray misses it or cannot find anything closer than its best hit there.
+// n* / f*: the box's near and far plane per axis for this ray (its min or max bound, by the sign of the direction).
+__device__ __forceinline__ float wide_child(f3 inv, f3 noi, float limT, float nx, float ny, float nz, float fx, float fy, float fz) {
+    const float tmin = fmaxf(fmaxf(__builtin_fmaf(nx, inv.x, noi.x), __builtin_fmaf(ny, inv.y, noi.y)), fmaxf(__builtin_fmaf(nz, inv.z, noi.z), 0.0f));
+    const float tmax = fminf(fminf(__builtin_fmaf(fx, inv.x, noi.x), __builtin_fmaf(fy, inv.y, noi.y)), fminf(__builtin_fmaf(fz, inv.z, noi.z), limT));
+    return tmin <= tmax ? tmin : INFINITY;
+}
+
+#define RT_WIDE_CSWAP(da, ea, db, eb)            \
+    do {                                         \
+        const bool sw_ = db < da;                \
+        const float dt_ = sw_ ? db : da;         \
+        const int et_ = sw_ ? eb : ea;           \
+        db = sw_ ? da : db;                      \
+        eb = sw_ ? ea : eb;                      \
+        da = dt_;                                \
+        ea = et_;                                \
+    } while (0)
+
+// One visit of a wide shortcut node (trav_at_wide(t)).  cache_base / n_cached as in trav_step_inner; both items of the
+// node must be inside the window for the LDS path.
+template <bool STATS, bool ALL_CACHED>
+__device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached, int cache_base) {
+    // a0..a2: the NEAR planes of the four children (x, y, z), b0..b2 the FAR ones, a3 the entries.  Which of a node's min / max
+    // pieces that is follows from the sign of the ray's direction (Trav::sgx..): the addresses differ, not the arithmetic.
+    float4 a0, a1, a2, a3, b0, b1, b2;
+    const int rel = t.cur - cache_base;
+    if (ALL_CACHED || (unsigned)rel < (unsigned)(n_cached - 1)) {
+        if (STATS) cn.dev_cached += 2;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f;
+        static_assert(RT_LDS_REC == 5, "Trav::sgx.. assume records of five float4s per item in the LDS window");
+        typedef const volatile __attribute__((address_space(3))) char* lds_bytes;
+        const lds_bytes c = (lds_bytes)rt_lds + 16 * RT_LDS_SLOT(rel, 0, n_cached);
+        const v4f p0 = *(lds_v4f)(c + t.sgx), p1 = *(lds_v4f)(c + t.sgy + 16), p2 = *(lds_v4f)(c + t.sgz + 32), p3 = *(lds_v4f)(c + 48),
+                  p4 = *(lds_v4f)(c - t.sgx + 80), p5 = *(lds_v4f)(c - t.sgy + 96), p6 = *(lds_v4f)(c - t.sgz + 112);
+        a0 = make_float4(p0.x, p0.y, p0.z, p0.w); a1 = make_float4(p1.x, p1.y, p1.z, p1.w); a2 = make_float4(p2.x, p2.y, p2.z, p2.w);
+        a3 = make_float4(p3.x, p3.y, p3.z, p3.w); b0 = make_float4(p4.x, p4.y, p4.z, p4.w); b1 = make_float4(p5.x, p5.y, p5.z, p5.w);
+        b2 = make_float4(p6.x, p6.y, p6.z, p6.w);
+    } else {
+        // (32-bit byte offsets from the first wide node: the range of wide nodes is far below 4 GB; uniform base + lane offset)
+        const char* wb = (const char*)(sc.items + 4 * (size_t)sc.wide_lo);
+        const unsigned o = (unsigned)(t.cur - sc.wide_lo) * 64u;
+        const unsigned gx = (unsigned)t.sgx & 64u, gy = (unsigned)t.sgy & 64u, gz = (unsigned)t.sgz & 64u;
+        a0 = *(const float4*)(wb + (o + gx)); a1 = *(const float4*)(wb + (o + gy + 16u)); a2 = *(const float4*)(wb + (o + gz + 32u));
+        a3 = *(const float4*)(wb + (o + 48u));
+        b0 = *(const float4*)(wb + (o - gx + 64u)); b1 = *(const float4*)(wb + (o - gy + 80u)); b2 = *(const float4*)(wb + (o - gz + 96u));
+        asm volatile("" : "+v"(a3.x), "+v"(a3.y), "+v"(a3.z), "+v"(a3.w));  // (16-byte loads, all issued before the first use)
+    }
+    if (STATS) { cn.dev_inner += 2; cn.dev_wide++; }
+    if (t.sp > sc.wide_sp_max) {  // no room for three more entries: give up, the reference's walk decides (short_certified)
+        t.bestLeaf = -2;
+        t.cur = RT_TRAV_DONE;
+        return;
+    }
+    const f3 inv = t.inv();
+    const f3 noi = mk(-(t.oxy.x * inv.x), -(t.oxy.y * inv.y), -(t.oz * inv.z));
+    float d0 = wide_child(inv, noi, t.limT, a0.x, a1.x, a2.x, b0.x, b1.x, b2.x);
+    float d1 = wide_child(inv, noi, t.limT, a0.y, a1.y, a2.y, b0.y, b1.y, b2.y);
+    float d2 = wide_child(inv, noi, t.limT, a0.z, a1.z, a2.z, b0.z, b1.z, b2.z);
+    float d3 = wide_child(inv, noi, t.limT, a0.w, a1.w, a2.w, b0.w, b1.w, b2.w);
+    int e0 = __float_as_int(a3.x), e1 = __float_as_int(a3.y), e2 = __float_as_int(a3.z), e3 = __float_as_int(a3.w);
+#if RT_WIDE_SORT
+    RT_WIDE_CSWAP(d0, e0, d1, e1);
+    RT_WIDE_CSWAP(d2, e2, d3, e3);
+    RT_WIDE_CSWAP(d0, e0, d2, e2);
+    RT_WIDE_CSWAP(d1, e1, d3, e3);
+    RT_WIDE_CSWAP(d1, e1, d2, e2);
+#else
+    RT_WIDE_CSWAP(d0, e0, d1, e1);  // the nearest to the front, the rest as they are
+    RT_WIDE_CSWAP(d0, e0, d2, e2);
+    RT_WIDE_CSWAP(d0, e0, d3, e3);
+#endif
+    // far ones first; an entry that is not hit is written too and left above the stack pointer (no branches)
+    stk[t.sp * 64] = e3; t.sp += d3 < INFINITY;
+    stk[t.sp * 64] = e2; t.sp += d2 < INFINITY;
+    stk[t.sp * 64] = e1; t.sp += d1 < INFINITY;
+    if (d0 < INFINITY) t.cur = e0;
+    else trav_pop(t, stk);
+}
+
 // TLDS: a scene so small that its WHOLE item stream sits in the LDS cache (n_cached = inner items + triangles).
 template <bool STATS, bool SUB, bool TLDS = false, bool FAST = false>
 __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int n_cached = 0) {  // a triangle or RT_TRAV_EMPTY
@@ -675,7 +809,12 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
 // reaches, so the reference finds none either --, or the search already was the reference's walk).
 __device__ __forceinline__ void short_begin(const Scene& sc, Trav& t) {
     t.bestLeaf = -1;
-    if (t.cur != RT_TRAV_DONE && !t.axis_parallel && t.slack < INFINITY) {
+    // (wide nodes form bound / d - o / d: o / d must be finite, or a box the ray reaches could test as missed)
+    const bool finite_od = sc.wide_n == 0 || (fabsf(t.oxy.x * t.ixy.x) < INFINITY && fabsf(t.oxy.y * t.ixy.y) < INFINITY && fabsf(t.oz * t.iz) < INFINITY);
+    t.sgx = t.ixy.x < 0.0f ? 80 : 0;
+    t.sgy = t.ixy.y < 0.0f ? 80 : 0;
+    t.sgz = t.iz < 0.0f ? 80 : 0;
+    if (t.cur != RT_TRAV_DONE && !t.axis_parallel && t.slack < INFINITY && finite_od) {
         t.cur = sc.short_root;
         t.rival = 1e12f;
     } else {
@@ -683,7 +822,9 @@ __device__ __forceinline__ void short_begin(const Scene& sc, Trav& t) {
     }
 }
 __device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t) {
-    if (t.rival < 0.0f || t.hitTri < 0) return true;
+    if (t.rival < 0.0f) return true;
+    if (t.bestLeaf == -2) return false;  // the search gave up (stack room, trav_step_wide)
+    if (t.hitTri < 0) return true;
     const int leaf = __float_as_int(sc.items[4 * ((size_t)sc.n_inner + t.hitTri) + 3].x);
     const float4 mn = sc.ref_boxes[2 * (size_t)leaf], mx = sc.ref_boxes[2 * (size_t)leaf + 1];
     const float bd = aabb_distance(t.o(), t.inv(), mk(mn.x, mn.y, mn.z), mk(mx.x, mx.y, mx.z));

@@ -5,10 +5,12 @@ Bit-identity with the oracle at the same seed (tests/test_gpu_parity.py) cannot 
 biased layout of the RNG dimensions, an estimator that loses energy.  These tests can:
   * independent seeds: GPU at seed A against the oracle at seeds B and C, 128 x 128, 1024 spp --
     |mean luminance(gpu_A) / mean luminance(orc_B) - 1| <= 1 % and RMSE(gpu_A, orc_B) <= 1.5 RMSE(orc_C, orc_B);
+    on the BASELINE scenes as configured (Cornell box, scene.txt under the HDR sky), where one seed scatters by 3 %, the same
+    1 % against the mean of 128 committed oracle seeds and 512 GPU seeds (tests/golden/conv_*.npz);
   * two GPU seeds approach each other as 1 / sqrt(spp) over 64 -> 256 -> 1024 spp;
   * known answers whatever the random numbers: an emissive wall, a white furnace (white Lambertian mesh in a
     constant environment: every pixel = the environment, geometry invisible), the cosine-weighted mean 2/3.
-The tolerances are the ones SURVEY.md fixed; they are not renegotiated here."""
+The tolerances are the ones SURVEY.md fixed, as constants: no bound here scales with a measured scatter."""
 import numpy as np
 import pytest
 
@@ -30,35 +32,70 @@ def gpu_average(rt, gpu, sc, seed, spp, size=128, bounces=6, flags=None):
     return gpu.readback(rt.READ_AVERAGE), p
 
 
-@pytest.mark.parametrize("name,skybox,spp", [("scene.txt", False, 1024), ("scene2.txt", False, 256),
-                                             ("scene_cornellbox.txt", True, 1024), ("scene.txt", True, 1024)])
-def test_converged_image_against_independent_oracle_seeds(ob, rt, gpu, scenes, name, skybox, spp):
-    """SURVEY 8(c)(ii).  The 1 % luminance bound only says something where the estimator's own seed-to-seed scatter is
-    far below it: measured on this GPU (tools/gpu_lum_noise.py -> profiles/r02_lum_noise.txt), 128 x 128 renders under
-    the flat backdrop scatter by 0.006 % (scene.txt) / 0.011 % (scene2.txt) at 1024 spp, but the Cornell box (a small
-    light found by chance) and scene.txt under the HDR sun by 2.1 % / 2.6 % at 1024 spp and still 0.6 % / 0.85 % at
-    16 384 spp.  So: flat-backdrop cases carry the bound as fixed; for the two firefly-dominated cases the same check
-    runs with the allowance widened to four times the scatter measured here on eight GPU seeds, and the RMSE criterion
-    (self-calibrating: it is relative to what two oracle seeds differ by) applies to all four."""
+def lum(img):
+    return float((img.reshape(-1, 3).astype(np.float64) @ LUMA).mean())
+
+
+@pytest.mark.parametrize("name,spp", [("scene.txt", 1024), ("scene2.txt", 256)])
+def test_converged_image_against_independent_oracle_seeds(ob, rt, gpu, scenes, name, spp):
+    """SURVEY 8(c)(ii) on the flat backdrop (seed-to-seed scatter of the mean luminance 0.006 % / 0.011 % at these sample
+    counts, profiles/r02_lum_noise.txt): GPU at seed A against the oracle at seeds B and C, the oracle rendered here."""
     sc = scenes(name)
     gpu.upload(sc)
-    flags = rt.F_DEFAULT if skybox else rt.F_DEFAULT & ~rt.F_SKYBOX
+    flags = rt.F_DEFAULT & ~rt.F_SKYBOX
     g, p = gpu_average(rt, gpu, sc, seed=1001, spp=spp, flags=flags)
     ref = []
     for seed in (2002, 3003):
         q = rt.RenderParams.from_buffer_copy(p); q.seed = seed
         acc, _ = ob.render(sc, q, n_threads=16)
         ref.append(acc / np.float32(spp))
-    lum = lambda img: float((img.reshape(-1, 3).astype(np.float64) @ LUMA).mean())
-    allow = 0.01                                                                  # the bound SURVEY fixed
-    if skybox:
-        seeds = [lum(gpu_average(rt, gpu, sc, seed=5000 + k, spp=spp, flags=flags)[0]) for k in range(8)]
-        scatter = float(np.std(seeds, ddof=1) / np.mean(seeds))
-        allow = max(allow, 4.0 * np.sqrt(2.0) * scatter)                          # difference of two seeds: sqrt(2) x one seed's
-    assert abs(lum(g) / lum(ref[0]) - 1.0) <= allow, (lum(g), lum(ref[0]), allow)
+    assert abs(lum(g) / lum(ref[0]) - 1.0) <= 0.01, (lum(g), lum(ref[0]))          # the bound SURVEY fixed
     noise = rmse(ref[1], ref[0])                                                  # what two reference-code seeds differ by
     assert noise > 0 and rmse(g, ref[0]) <= 1.5 * noise, (rmse(g, ref[0]), noise)
     assert rmse(g, ref[1]) <= 1.5 * noise
+
+
+@pytest.mark.parametrize("name", ["scene_cornellbox.txt", "scene.txt"])
+def test_converged_luminance_of_the_baseline_scenes_as_configured(rt, gpu, scenes, name):
+    """The SAME fixed bounds on the scenes BASELINE.json names as they are configured: the Cornell box, whose small light is
+    found by chance (material.h:205-213), and scene.txt under the HDR environment (main.cu:374-383).  One seed of 1 024 spp
+    scatters by 2.8 % / 3 % in mean luminance there (fireflies), so one pair of seeds cannot carry a 1 % bound; many can.
+    tests/golden/conv_<scene>.npz holds K = 128 independent ORACLE seeds (tools/make_converged_golden.py, build container):
+    per-seed mean luminance, the mean image, the first two seeds' images.  Here the GPU renders K' = 512 OTHER seeds:
+        | mean_gpu / mean_oracle - 1 | <= 1 %           (standard error of the ratio ~ 0.3 %: a 3-sigma test, no scatter-scaled term)
+        RMSE(gpu seed, oracle seed A) <= 1.5 RMSE(oracle seed A, oracle seed B)      for the first GPU seeds, as SURVEY states it
+    and, beyond SURVEY's two criteria, the two MEAN images agree as far as seed noise lets means of K and K' seeds agree:
+        RMSE(mean image gpu, mean image oracle) <= 2 x noise / sqrt(2) x sqrt(1 / K + 1 / K')."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv_" + name.replace(".txt", "") + ".npz"))
+    size, spp, bounces, K = int(fx["size"]), int(fx["spp"]), int(fx["bounces"]), len(fx["lum"])
+    assert K >= 64 and int(fx["flags"]) == rt.F_DEFAULT
+    sc = scenes(name)
+    gpu.upload(sc)
+    KG = 512
+    lums, mean = np.zeros(KG), np.zeros((size, size, 3), np.float64)
+    first = []
+    for k in range(KG):
+        img, _ = gpu_average(rt, gpu, sc, seed=200000 + k, spp=spp, size=size, bounces=bounces)   # (oracle seeds: 100000 + k)
+        lums[k] = lum(img)
+        mean += img
+        if k < 4:
+            first.append(img)
+    mean /= KG
+    ratio = lums.mean() / fx["lum"].mean()
+    se = np.hypot(lums.std(ddof=1) / np.sqrt(KG) / lums.mean(), fx["lum"].std(ddof=1) / np.sqrt(K) / fx["lum"].mean())
+    print(f"{name}: mean luminance gpu {lums.mean():.6f} ({KG} seeds) / oracle {fx['lum'].mean():.6f} ({K} seeds) = {ratio:.5f}, "
+          f"standard error of the ratio {100 * se:.2f} %, per-seed scatter gpu {100 * lums.std(ddof=1) / lums.mean():.2f} % / "
+          f"oracle {100 * fx['lum'].std(ddof=1) / fx['lum'].mean():.2f} %")
+    assert abs(ratio - 1.0) <= 0.01                                              # the bound SURVEY fixed, as a constant
+    assert se < 0.004                                                             # ... and it means something: 1 % is > 2.5 sigma
+    noise = rmse(fx["ref_b"], fx["ref_a"])                                        # what two reference-code seeds differ by
+    for img in first:
+        assert rmse(img, fx["ref_a"]) <= 1.5 * noise and rmse(img, fx["ref_b"]) <= 1.5 * noise
+    # the two mean images differ by seed noise only: single-seed noise sigma_1 = noise / sqrt(2) per pixel, means of K and K' seeds
+    predicted = noise / np.sqrt(2.0) * np.sqrt(1.0 / K + 1.0 / KG)
+    print(f"{name}: RMSE of the mean images {rmse(mean, fx['mean_image']):.5f}, predicted from seed noise {predicted:.5f}")
+    assert rmse(mean, fx["mean_image"]) <= 2.0 * predicted, (rmse(mean, fx["mean_image"]), predicted)
 
 
 def test_two_gpu_seeds_converge_as_inverse_sqrt_spp(rt, gpu, scenes):

@@ -30,6 +30,32 @@ def as_int(a):
     return np.ascontiguousarray(a, np.float32).view(np.int32)
 
 
+def kinds_of(items, info):
+    """Per inner item: 0 the reference's node, 1 sub-tree node, 2 two-child shortcut node, 3 / 4 first / second item of a
+    wide (four-child) shortcut node (csrc/rt_device.h)."""
+    kind = as_int(items[:info.n_inner, 15]).copy()
+    lo = info.short_base
+    kind[lo:lo + 2 * info.n_wide:2] = 3
+    kind[lo + 1:lo + 2 * info.n_wide:2] = 4
+    return kind
+
+
+def wide_children(items, info, entry):
+    """(entry, box) of the children of the wide node whose first item is `entry`."""
+    w0, w1 = items[entry], items[entry + 1]
+    nk = int(as_int(w1[12:13])[0])
+    assert 2 <= nk <= 4 and int(as_int(w1[15:16])[0]) == 3
+    out = []
+    for i in range(4):
+        box = np.array([w0[i], w0[4 + i], w0[8 + i], w1[i], w1[4 + i], w1[8 + i]], F)
+        e = int(as_int(w0[12 + i:13 + i])[0])
+        if i < nk:
+            out.append((e, box))
+        else:
+            assert e == EMPTY and (box == F(3e38)).all()
+    return out
+
+
 def unpack(items, info):
     inner = items[:info.n_inner]
     tri = items[info.n_inner:]
@@ -38,6 +64,7 @@ def unpack(items, info):
     entries = as_int(inner[:, 12:14])
     third = as_int(inner[:, 14])
     is_sub = as_int(inner[:, 15]) == 1                                 # (2 = a node of the shortcut tree)
+    is_sub[info.short_base:info.short_base + 2 * info.n_wide] = False  # (wide shortcut nodes: two items each, other fields)
     flags, leaf_end, ids = as_int(tri[:, 9]), as_int(tri[:, 10]), as_int(tri[:, 11])
     return boxes, entries, third, is_sub, flags, leaf_end, ids
 
@@ -59,9 +86,12 @@ def test_presorted_sweep_builds_the_same_sub_trees(rt, monkeypatch, seed, n, dep
     assert np.array_equal(as_int(items_a), as_int(items_b)) and np.array_equal(places_a, places_b)
 
 
+@pytest.mark.parametrize("binary", [False, True])
 @pytest.mark.parametrize("seed,n,depth,by_leaves", [(1, 900, 4, False), (2, 3000, 16, False), (3, 400, 1, False), (1, 900, 4, True),
                                                    (2, 3000, 16, True), (4, 200, 3, "single"), (1, 900, 4, "cut2"), (3, 400, 1, "cut3")])
-def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
+def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves, binary):
+    if binary:
+        monkeypatch.setenv("RT_SHORT_BINARY", "1")                     # the two-child form of the shortcut tree (experiments)
     single = by_leaves == "single"                                     # a scene too small for sub-trees: shortcut tree over single triangles
     cut = int(by_leaves[3:]) if isinstance(by_leaves, str) and by_leaves.startswith("cut") else 0
     by_leaves = by_leaves is True or cut > 0
@@ -74,7 +104,8 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     boxes, entries, third, is_sub, flags, leaf_end, ids = unpack(items, info)
     nodes, tris = sc.nodes(), sc.tris()
     assert info.n_tris == n and info.n_sub == is_sub.sum() and (single or info.n_sub > 0) and info.root_entry == 0
-    assert bool(info.short_single) == single and (not single or info.n_short == n - 1)
+    assert bool(info.short_single) == single and (not single or binary or 3 * info.n_short + 1 >= n) and (not single or not binary or info.n_short == n - 1)
+    assert (info.n_wide == 0) == binary and (binary or info.n_wide == info.n_short)
     assert sorted(places.tolist()) == list(range(n)) and np.array_equal(ids[places], np.arange(n))
     v = tris[:, :9].reshape(n, 3, 3)
     placed = v[ids]                                                    # triangle geometry in item order
@@ -82,7 +113,7 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     assert np.array_equal(got[:, 0], placed[:, 0]) and np.array_equal(got[:, 1], placed[:, 1] - placed[:, 0])
     # reference nodes: boxes and ids as uploaded, children in the reference's A / B order
     ref_inner = [i for i in range(len(nodes)) if nodes[i]["child_a"] != -1]
-    kind = as_int(items[:info.n_inner, 15])                            # 0 the reference's node, 1 sub-tree node, 2 shortcut node
+    kind = kinds_of(items, info)                                       # 0 the reference's node, 1 sub-tree node, 2 shortcut node, 3 / 4 wide shortcut node
     by_ref = {int(third[k]): k for k in range(info.n_inner) if kind[k] == 0}
     assert sorted(by_ref) == ref_inner
     for i in ref_inner:
@@ -136,7 +167,8 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
     assert depth_seen <= info.depth <= 24
     # the shortcut tree: every non-empty reference leaf hangs below it exactly once, with what the reference's tree has
     # below that leaf (its first triangle or its sub-tree); padded boxes hold everything below them
-    assert info.n_short == (kind == 2).sum() > 0 and kind[info.short_root] == 2
+    assert info.n_short == (kind == (2 if binary else 3)).sum() > 0 and kind[info.short_root] == (2 if binary else 3)
+    assert (kind == 4).sum() == info.n_wide and (binary or info.short_root == info.short_base)   # (the root has the biggest box)
     assert info.short_base + 1 <= info.n_inner and info.short_base <= 1024
     leaf_entries = {}
     for k in range(info.n_inner):
@@ -162,20 +194,22 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves):
             if entry >= info.n_inner:
                 return walk(entry, d, bool(flags[entry - info.n_inner] & 4))
             return walk(entry, d, third[entry] == 0)
-        assert entry < info.n_inner and kind[entry] == 2
+        assert entry < info.n_inner and kind[entry] == (2 if binary else 3)
         below = []
-        for side in range(2):
-            got_below = walk_short(int(entries[entry, side]), d + 1)
+        kids = [(int(entries[entry, side]), boxes[entry, side]) for side in range(2)] if binary else wide_children(items, info, entry)
+        for k, (e, box) in enumerate(kids):
+            got_below = walk_short(e, d + 1)
             pts = placed[got_below].reshape(-1, 3)
-            assert (boxes[entry, side, :3] <= pts.min(0) - 0.5 * info.box_pad).all()
-            assert (boxes[entry, side, 3:] >= pts.max(0) + 0.5 * info.box_pad).all()
+            assert (box[:3] <= pts.min(0) - 0.5 * info.box_pad).all()
+            assert (box[3:] >= pts.max(0) + 0.5 * info.box_pad).all()
             below += got_below
         return below
 
     walk_short(info.short_root, 0)
     assert (seen == 1).all() and (not by_leaves or cut > 0 or sorted(reached) == sorted(leaf_entries))
     assert info.short_cut == cut and (cut == 0 or len(reached) < len(leaf_entries))
-    assert depth_seen <= info.short_depth <= 32
+    assert binary or info.wide_sp_max >= 3
+    assert (depth_seen <= info.short_depth <= 32) if binary else (info.short_depth <= 32 and info.wide_sp_max + 3 <= max(info.depth, info.short_depth))
     leaf_of = as_int(items[info.n_inner:, 12])                        # every triangle names its reference leaf
     for nd_i, nd in enumerate(nodes):
         if nd["child_a"] == -1 and nd["tri_len"] > 0:
@@ -218,14 +252,38 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
         def cross(a, b):
             return np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], F)
 
+        def fma(a, b, c):                                                 # (a * b is exact in float64)
+            return F(np.float64(a) * np.float64(b) + np.float64(c))
+
         def search(start, fast):
             min_d2, hit, hit_t = F(1e12), -1, F(0)
             rival, best_leaf = F(1e12), -1
             sub_lim = (min_d2 * F(1.00002) + slack) * inv_d2
             stack, cur, eps = [], start, F(1e-9)
+            wide_lo, wide_hi = info.short_base, info.short_base + 2 * info.n_wide
             while True:
                 if cur == EMPTY:
                     pass
+                elif fast and wide_lo <= cur < wide_hi:                    # rt_device.h: trav_step_wide
+                    if len(stack) > info.wide_sp_max:
+                        return -2, min_d2, hit_t, rival                    # gave up: the reference's walk decides
+                    lim_t = np.sqrt(sub_lim, dtype=F) * F(1.00001)
+                    noi = -(o * inv)
+                    kids = []
+                    w0, w1 = items[cur], items[cur + 1]
+                    for i in range(4):
+                        lo3 = [fma(w0[4 * k + i], inv[k], noi[k]) for k in range(3)]
+                        hi3 = [fma(w1[4 * k + i], inv[k], noi[k]) for k in range(3)]
+                        tmin = max(max(min(lo3[0], hi3[0]), min(lo3[1], hi3[1])), max(min(lo3[2], hi3[2]), F(0)))
+                        tmax = min(min(max(lo3[0], hi3[0]), max(lo3[1], hi3[1])), min(max(lo3[2], hi3[2]), lim_t))
+                        if tmin <= tmax:
+                            kids.append((tmin, i, int(as_int(w0[12 + i:13 + i])[0])))
+                    kids.sort()
+                    for _, _, e in reversed(kids[1:]):
+                        stack.append(e)
+                    if kids:
+                        cur = kids[0][2]
+                        continue
                 elif cur < info.n_inner:
                     w = items[cur]
                     bA = np.array([w[0], w[1], w[8], w[2], w[3], w[9]], F)
@@ -284,9 +342,12 @@ def trace_on_items(info, items, o, d, shortcut=False, nodes=None):
             root_ok = box_dist(np.concatenate([root["bbox_min"], root["bbox_max"]]).astype(F)) <= F(1e12)
             if not root_ok:
                 return -1, F(-1), False
-            usable = np.isfinite(inv).all() and np.isfinite(slack)
+            usable = np.isfinite(inv).all() and np.isfinite(slack) and (info.n_wide == 0 or np.isfinite(o * inv).all())
             hit, min_d2, hit_t, rival = search(info.short_root if usable else info.root_entry, usable)
-            if usable and hit >= 0:
+            if usable and hit == -2:                                   # the wide walk ran out of stack room
+                rewalked = True
+                hit, min_d2, hit_t, rival = search(info.root_entry, False)
+            elif usable and hit >= 0:
                 leaf = nodes[int(as_int(items[info.n_inner + hit][12:13])[0])]
                 bd = box_dist(np.concatenate([leaf["bbox_min"], leaf["bbox_max"]]).astype(F))
                 bd2 = bd * bd
