@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_REF_FRONT 1024        // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
-#define RT_WIDE_STACK 15         // stack entries a search of the WIDE shortcut tree may use for itself (a deeper path gives up and walks the reference's tree)
+#define RT_WIDE_STACK 12         // stack entries a search of the WIDE shortcut tree may use for itself (a deeper path gives up and walks the reference's tree)
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
 #define RT_SHORT_FRONT_MAX (1 << 18)  // ... with at most this many entries (the 10M-triangle field, 4 spp frames: leaves 15.56 ms, 2 levels below them --
                                       // 262 k entries, 25 ms of build -- 14.43, 4 levels -- 1 M, 96 ms -- 14.43, 6 levels 14.49, runs -- 6.2 M, 0.5 s -- 13.8 to 14.5)
@@ -2291,6 +2291,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     struct WideNode { float box[4][6]; int e[4]; int nk; };  // e >= 0: wide node; e < 0: ~(ShortPrim::node of what hangs there); slots >= nk unused
     std::vector<WideNode> wides;
     int wide_root = -1, wide_need = 0;  // (stack entries a search of the wide tree can need: sum of (children - 1) down the worst path)
+    int n_wide_top = 0;                 // wide nodes of the shortcut tree proper (the others: wide forms of sub-tree parts, huge scenes)
     if (short_root >= 0 && !getenv("RT_SHORT_BINARY")) {
         wides.reserve(shorts.size() / 2 + 1);
         auto collapse = [&](auto&& self, int bnode, int& need) -> int {
@@ -2331,6 +2332,88 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         };
         wide_root = collapse(collapse, short_root, wide_need);
         shorts.clear();
+        n_wide_top = (int)wides.size();
+        if (!short_runs && !getenv("RT_WIDE_TOP_ONLY")) {
+            // The shortcut tree stands over a frontier of the leaves' sub-trees (huge scenes): what hangs below the frontier is
+            // collapsed into wide nodes as well -- a second, four-child form of those parts of the sub-trees, for the shortcut walk
+            // alone (the reference's walk keeps the two-child nodes) --, so that a shortcut search meets ONE kind of inner node.
+            struct Task { int w, i, sub; };
+            std::vector<Task> tasks;
+            for (int w = 0; w < n_wide_top; w++)
+                for (int i = 0; i < wides[(size_t)w].nk; i++) {
+                    const int e = wides[(size_t)w].e[i];
+                    if (e < 0 && (~e & 1)) tasks.push_back({w, i, ~e >> 1});
+                }
+            auto collapse_sub = [&](auto&& self, std::vector<WideNode>& out, int bnode, int& need) -> int {
+                const float* kbox[4];
+                int ke[4], nk = 2;
+                kbox[0] = subs[(size_t)bnode].box[0]; ke[0] = subs[(size_t)bnode].e[0];
+                kbox[1] = subs[(size_t)bnode].box[1]; ke[1] = subs[(size_t)bnode].e[1];
+                while (nk < 4) {
+                    int best = -1;
+                    float ba = -1.f;
+                    for (int i = 0; i < nk; i++)
+                        if (ke[i] >= 0 && half_area(kbox[i]) > ba) { ba = half_area(kbox[i]); best = i; }
+                    if (best < 0) break;
+                    const SubNode& c = subs[(size_t)ke[best]];
+                    kbox[best] = c.box[0]; ke[best] = c.e[0];
+                    kbox[nk] = c.box[1]; ke[nk] = c.e[1];
+                    nk++;
+                }
+                const int idx = (int)out.size();
+                out.push_back(WideNode());
+                WideNode nd;
+                nd.nk = nk;
+                int below = 0;
+                for (int i = 0; i < 4; i++) {
+                    if (i < nk) {
+                        memcpy(nd.box[i], kbox[i], 6 * sizeof(float));
+                        int nb = 0;
+                        nd.e[i] = ke[i] >= 0 ? self(self, out, ke[i], nb) : ~(2 * ~ke[i]);  // (a sub-leaf: the run of triangles at place ~ke)
+                        below = std::max(below, nb);
+                    } else {
+                        for (int k = 0; k < 6; k++) nd.box[i][k] = 3e38f;
+                        nd.e[i] = 0;
+                    }
+                }
+                out[(size_t)idx] = nd;
+                need = nk - 1 + below;
+                return idx;
+            };
+            std::vector<std::vector<WideNode>> loc((size_t)n_workers_max);
+            std::vector<int> task_root(tasks.size(), 0), need_max((size_t)n_workers_max, 0), task_worker(tasks.size(), 0);
+            const int nw = par_ranges(tasks.size(), [&](int wi, size_t lo, size_t hi) {
+                for (size_t k = lo; k < hi; k++) {
+                    int need = 0;
+                    task_root[k] = collapse_sub(collapse_sub, loc[(size_t)wi], tasks[k].sub, need);
+                    task_worker[k] = wi;
+                    need_max[(size_t)wi] = std::max(need_max[(size_t)wi], need);
+                }
+            });
+            std::vector<size_t> off((size_t)nw + 1, (size_t)n_wide_top);
+            for (int wi = 0; wi < nw; wi++) off[(size_t)wi + 1] = off[(size_t)wi] + loc[(size_t)wi].size();
+            wides.resize(off[(size_t)nw]);
+            {
+                std::vector<std::thread> th;
+                auto copy = [&](int wi) {
+                    const int o = (int)off[(size_t)wi];
+                    for (size_t k = 0; k < loc[(size_t)wi].size(); k++) {
+                        WideNode nd = loc[(size_t)wi][k];
+                        for (int i = 0; i < nd.nk; i++)
+                            if (nd.e[i] >= 0) nd.e[i] += o;
+                        wides[(size_t)o + k] = nd;
+                    }
+                };
+                for (int wi = 1; wi < nw; wi++) th.emplace_back(copy, wi);
+                copy(0);
+                for (auto& t : th) t.join();
+            }
+            int sub_need = 0;
+            for (size_t k = 0; k < tasks.size(); k++) wides[(size_t)tasks[k].w].e[tasks[k].i] = (int)off[(size_t)task_worker[k]] + task_root[k];
+            for (int wi = 0; wi < nw; wi++) sub_need = std::max(sub_need, need_max[(size_t)wi]);
+            wide_need += sub_need;   // (an upper bound: the deepest frontier part below the deepest path of the shortcut tree)
+            below_leaf = 0;          // a shortcut search no longer enters the two-child sub-trees
+        }
     }
     const int n_wide = (int)wides.size();
     const int n_short = (int)shorts.size();
@@ -2413,8 +2496,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             // head of that range), the others in tree order; then every other reference node and the sub-tree nodes
             big = select(1, front ? std::min<size_t>(RT_REF_FRONT, (size_t)n_top) : 0);
             short_base = (int)big.size();
-            std::vector<std::pair<float, int>> wk((size_t)n_wide);
-            for (int w = 0; w < n_wide; w++) {
+            std::vector<std::pair<float, int>> wk((size_t)n_wide_top);  // (the wide forms of sub-tree parts have the smaller boxes: never in front)
+            for (int w = 0; w < n_wide_top; w++) {
                 float u[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
                 for (int i = 0; i < wides[(size_t)w].nk; i++)
                     for (int c = 0; c < 3; c++) {
@@ -2423,12 +2506,15 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     }
                 wk[(size_t)w] = {w == wide_root ? 3e38f : half_area(u), w};
             }
-            const size_t nf = std::min<size_t>(front, (size_t)n_wide);
+            const size_t nf = std::min<size_t>(front, (size_t)n_wide_top);
             auto wbigger = [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; };
-            std::partial_sort(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wk.end(), wbigger);
-            std::sort(wk.begin() + (std::ptrdiff_t)nf, wk.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.second < b.second; });
-            wide_index.assign((size_t)n_wide, 0);
-            for (int k = 0; k < n_wide; k++) wide_index[(size_t)wk[(size_t)k].second] = short_base + 2 * k;
+            std::nth_element(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wk.end(), wbigger);
+            std::sort(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wbigger);
+            wide_index.assign((size_t)n_wide, -1);
+            for (size_t k = 0; k < nf; k++) wide_index[(size_t)wk[k].second] = short_base + 2 * (int)k;
+            int next = short_base + 2 * (int)nf;
+            for (int w = 0; w < n_wide; w++)
+                if (wide_index[(size_t)w] < 0) { wide_index[(size_t)w] = next; next += 2; }
             rest_base = (size_t)short_base + 2 * (size_t)n_wide;
         } else if (n_short > 0 && front) {
             big = select(1, std::min<size_t>(RT_REF_FRONT, (size_t)n_top));

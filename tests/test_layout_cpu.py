@@ -182,13 +182,14 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves, bina
 
     def walk_short(entry, d):
         nonlocal depth_seen
-        if entry >= info.n_inner and not by_leaves:                    # a run of triangles up to a 'last' flag (or ONE triangle)
+        if entry >= info.n_inner and (not by_leaves or not binary):    # a run of triangles up to a 'last' flag (or ONE triangle); the wide
+                                                                       # form has four-child nodes of its own all the way down to the runs
             depth_seen = max(depth_seen, d)
             run = [entry - info.n_inner] if info.short_single else leaf_run(entry - info.n_inner)
             assert info.short_single or entry == info.n_inner or flags[entry - info.n_inner - 1] & 1
             seen[run] += 1
             return run
-        if by_leaves and (entry >= info.n_inner or kind[entry] == 1):  # a leaf, or a node / sub-leaf of its sub-tree on the cut
+        if by_leaves and binary and (entry >= info.n_inner or kind[entry] == 1):  # a leaf, or a node / sub-leaf of its sub-tree on the cut
             if entry in leaf_entries:
                 reached.append(entry)
             if entry >= info.n_inner:
@@ -206,8 +207,8 @@ def test_item_stream_invariants(rt, monkeypatch, seed, n, depth, by_leaves, bina
         return below
 
     walk_short(info.short_root, 0)
-    assert (seen == 1).all() and (not by_leaves or cut > 0 or sorted(reached) == sorted(leaf_entries))
-    assert info.short_cut == cut and (cut == 0 or len(reached) < len(leaf_entries))
+    assert (seen == 1).all() and (not by_leaves or not binary or cut > 0 or sorted(reached) == sorted(leaf_entries))
+    assert info.short_cut == cut and (cut == 0 or not binary or len(reached) < len(leaf_entries))
     assert binary or info.wide_sp_max >= 3
     assert (depth_seen <= info.short_depth <= 32) if binary else (info.short_depth <= 32 and info.wide_sp_max + 3 <= max(info.depth, info.short_depth))
     leaf_of = as_int(items[info.n_inner:, 12])                        # every triangle names its reference leaf
