@@ -199,6 +199,8 @@ typedef struct rt_render_stats {
     /* round 3 */
     uint64_t dev_wide_visits;      /* visits of wide (four-child) shortcut nodes: 128 B each, counted as TWO items in dev_inner_visits /
                                       dev_lds_inner_visits */
+    uint64_t dev_light_loops;      /* type-5 bounces whose sum over the lights the light tree did not serve (rays it is not made for,
+                                      three or more nonzero terms, stack room): summed by the loop over every light instead */
 } rt_render_stats;
 
 enum { RT_READ_RAW_SUM = 0, RT_READ_AVERAGE = 1, RT_READ_TONEMAPPED = 2 };
@@ -354,6 +356,10 @@ typedef struct rt_layout_info {
                              short_base + 2 n_wide) (layout in csrc/rt_device.h); 0 = two-child shortcut nodes; n_short == n_wide then */
     int32_t wide_need;    /* stack entries the worst path of the wide tree needs */
     int32_t wide_sp_max;  /* a wide visit with more entries than this on the stack gives up (the ray walks the reference's tree) */
+    int32_t light_root;   /* item of the light tree's root (a wide node), -1 without one: the all-hits search that stands for
+                             reflectType5's loop over the lights (material.h:315-323) */
+    int32_t n_light_items; /* its leaves: light items [n_inner + n_tris + 1, + n_light_items), one per importance-sampled triangle */
+    int32_t light_need;   /* stack entries its worst path needs */
 } rt_layout_info;
 int rt_layout_create(const rt_scene_desc* scene, rt_layout** out, char* err_buf, size_t err_len);
 int rt_layout_get(const rt_layout* layout, rt_layout_info* info, const float** items, const int32_t** places); /* round 1's symbol: fills RT_LAYOUT_INFO_V1_SIZE bytes */

@@ -70,7 +70,7 @@ class RenderStats(C.Structure):
                 ("hits", C.c_uint64), ("texel_fetches", C.c_uint64), ("light_tests", C.c_uint64),
                 ("trace_ms", C.c_double), ("iterations", C.c_uint32), ("trace_launches", C.c_uint32),
                 ("dev_inner_visits", C.c_uint64), ("dev_lds_inner_visits", C.c_uint64), ("dev_tri_tests", C.c_uint64),
-                ("dev_light_tests", C.c_uint64), ("shortcut_rewalks", C.c_uint64), ("dev_wide_visits", C.c_uint64)]
+                ("dev_light_tests", C.c_uint64), ("shortcut_rewalks", C.c_uint64), ("dev_wide_visits", C.c_uint64), ("dev_light_loops", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -375,7 +375,8 @@ class LayoutInfo(C.Structure):  # rt_layout_info, include/rt.h
     _fields_ = [("n_inner", C.c_int32), ("n_sub", C.c_int32), ("n_tris", C.c_int32), ("root_entry", C.c_int32),
                 ("depth", C.c_int32), ("box_pad", C.c_float), ("cull_far", C.c_float), ("n_short", C.c_int32),
                 ("short_root", C.c_int32), ("short_base", C.c_int32), ("short_depth", C.c_int32), ("short_single", C.c_int32), ("short_cut", C.c_int32),
-                ("n_wide", C.c_int32), ("wide_need", C.c_int32), ("wide_sp_max", C.c_int32)]
+                ("n_wide", C.c_int32), ("wide_need", C.c_int32), ("wide_sp_max", C.c_int32),
+                ("light_root", C.c_int32), ("n_light_items", C.c_int32), ("light_need", C.c_int32)]
 
 
 def device_layout(scene: "Scene"):

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_CULL_FAR 8.f          // padded boxes cull only for rays that start within this many scene scales of the origin
 #define RT_ITEM_FRONT 8192       // inner items ordered by box area at the front of the item stream (what an LDS cache can hold, and more)
 #define RT_REF_FRONT 1024        // with a shortcut tree: this many of the reference's biggest nodes stand in front of the shortcut walk's window
+#define RT_LIGHT_TREE_FRONT_MAX 512  // wide nodes of a light tree that still goes into the LDS window (80 KB of it)
 #define RT_WIDE_STACK 12         // stack entries a search of the WIDE shortcut tree may use for itself (a deeper path gives up and walks the reference's tree)
 #define RT_SHORT_STACK_MAX 32    // stack entries the shortcut tree and the sub-trees below it may need together (256 B x 16 waves of LDS each)
 #define RT_SHORT_FRONT_MAX (1 << 18)  // ... with at most this many entries (the 10M-triangle field, 4 spp frames: leaves 15.56 ms, 2 levels below them --
@@ -248,6 +249,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_INNER_ROLLED
 #define RT_INNER_ROLLED 0
 #endif
+#ifndef RT_FINISH_MIN
+#define RT_FINISH_MIN 12        // lanes back from a light query that get a (short) vertex pass of their own
+#endif
 #ifndef RT_WIDE_STEPS
 #define RT_WIDE_STEPS 2         // visits of wide (four-child) shortcut nodes per vote
 #endif
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_REGEN_MIN_TINY 48    // vertex-pass vote there (40 / 44 / 48 / 52 / 56: 100.5 / 97.6 / 97.3 / 97.7 / 101.1 ms)
 #endif
 #ifndef RT_REGEN_MIN_COOP
-#define RT_REGEN_MIN_COOP 48    // ... in scenes whose vertex passes run the wave-cooperative light loop (scene2_is.txt 32 spp: 40 / 44 / 48 / 52 / 56 = 69.4 / 68.1 / 67.4 / 67.4 / 69.0 ms)
+#define RT_REGEN_MIN_COOP 40    // ... in scenes whose vertex passes run the wave-cooperative light loop (scene2_is.txt 32 spp: 40 / 44 / 48 / 52 / 56 = 69.4 / 68.1 / 67.4 / 67.4 / 69.0 ms)
 #endif
 #ifndef RT_NT_STORE
 #define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
@@ -339,12 +343,20 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     for (;;) {
         const unsigned long long mNeed = __ballot((unsigned)(t.cur + 2) < 2u);  // RT_TRAV_DONE or RT_LANE_NEW
         const unsigned long long mTrav = __ballot(t.cur >= 0);
-        if (__popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : COOP ? RT_REGEN_MIN_COOP : RT_REGEN_MIN) || mTrav == 0) {
+        // LTREE: reflectType5's sum over the lights runs as a search of the light tree (rt_device.h, LIGHT QUERY): the vertex pass that
+        // shades the hit starts it, the lane walks the light tree with its ordinary steps and comes back to a later pass, which
+        // finishes the bounce (finishing).  That second visit is short (the tail of reflectType5 and the start of the next search),
+        // so RT_FINISH_MIN lanes waiting for it get a pass of their own, which serves them alone (finish_only).
+        constexpr bool LTREE = FAST && COOP;
+        const bool finishing = LTREE && t.cur == RT_TRAV_DONE && t.bestLeaf <= RT_LQ_RUNNING;
+        const bool full_pass = __popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : COOP ? RT_REGEN_MIN_COOP : RT_REGEN_MIN) || mTrav == 0;
+        const bool finish_only = LTREE && !full_pass && __popcll(__ballot(finishing)) >= RT_FINISH_MIN;
+        if (full_pass || finish_only) {
             if (mNeed == 0) break;  // every lane idle: no paths left
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
             if ((unsigned)(t.cur + 2) < 2u) RT_PROF_LANE(cn, 4);
-            if (FAST && t.cur == RT_TRAV_DONE && !short_certified(sc, t)) {
+            if (FAST && !finish_only && t.cur == RT_TRAV_DONE && !finishing && !short_certified(sc, t)) {
                 // the shortcut walk's result does not prove what the reference's walk returns: this lane walks the
                 // reference's tree now (main.cu:221-283) and comes back to a later vertex pass
                 if (STATS) cn.rewalks++;
@@ -355,7 +367,8 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             PathState ray;
             f3 e = mk(0.f, 0.f, 0.f);  // what this path adds to its pixel
             bool alive = true;
-            const bool shading = t.cur == RT_TRAV_DONE;
+            const bool shading = t.cur == RT_TRAV_DONE && !finishing && !finish_only;
+            bool deferred = false;  // this lane's bounce goes on in a later pass, behind its light query
             LightQuery lq;
             lq.pending = false;
             if (shading) {  // one iteration of the bounce loop after the closest-hit search, main.cu:305-389
@@ -415,14 +428,59 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     }
                 }
             }
-            if (COOP && __ballot(lq.pending)) {  // material type 5 with many lights: its light loop, with the whole wave (rt_device.h)
+#ifdef RT_LQ_SKIP  // (timing experiments only: the sum over the lights taken as 0 -- a wrong image, the cost of everything else)
+            if (LTREE && lq.pending) {
+                finish_type5(sc, ray, lq, 0.0f);
+                ray.d = normalize_keep(ray.d);
+                lq.pending = false;
+            }
+#endif
+            if (LTREE) {
+                // pdf_cos > 2e-12: pdf = pdf_cos / 2 + pdf_light / 2 is then above reflectType5's 1e-12 whatever the lights add, so the
+                // finishing pass never needs the incoming direction (material.h:324-327 keeps it when the pdf vanishes)
+                if (lq.pending && sc.light_root >= 0 && lq.pdf_cos > 2e-12f && light_query_begin(sc, t, lq.hitPos, lq.outgoing, lq.pdf_cos)) {
+                    thr = ray.thr * lq.clr;  // (ray.thr * clr) * (pdf_cos / pdf): the first product now, the second when the sum is known
+                    ri = ray.ri;
+                    if (STATS) cn.lights += (uint32_t)sc.n_lights;  // what the reference's loop tests
+                    deferred = true;
+                    lq.pending = false;
+                }
+                // What the tree cannot serve -- a ray it is not made for (light_query_begin), a vanishing pdf_cos, and afterwards a query
+                // with three or more nonzero terms (their sum depends on the order) or one that ran out of stack -- is the reference's
+                // own loop over every light, in its order (light_pdf_loop).  Rare; the wave waits for the lanes that run it.
+                if (lq.pending) {
+                    if (STATS) cn.dev_light_loops++;
+                    const float pdf_light = light_pdf_loop<STATS>(sc, lq.hitPos, lq.outgoing, cn);
+                    finish_type5(sc, ray, lq, pdf_light);
+                    ray.d = normalize_keep(ray.d);  // main.cu:361
+                    lq.pending = false;
+                }
+                if (finishing) {  // the tail of reflectType5 (material.h:324-335) and main.cu:361
+                    if (t.hitTri > 2 || t.bestLeaf == RT_LQ_GAVE_UP) {
+                        if (STATS) cn.dev_light_loops++;
+                        Counters unused;  // (the deferral has counted this query's tests)
+                        unused.clear();
+                        t.minD2 = light_pdf_loop<false>(sc, t.o(), t.d, unused);
+                    }
+                    const float pdf_cos = t.hitT, pdf = 0.5f * pdf_cos + 0.5f * t.minD2;
+                    ray.o = t.o();
+                    ray.d = t.d;
+                    ray.thr = thr * (pdf_cos / pdf);
+                    ray.ri = ri;
+                    ray.emission = mk(0.f, 0.f, 0.f);
+                    ray.volDensity = 0.0f;
+                    ray.volColor = mk(1.f, 1.f, 1.f);
+                    ray.o = ray.o + ray.d * 1e-5f;
+                    ray.d = normalize_keep(ray.d);
+                }
+            } else if (COOP && __ballot(lq.pending)) {  // material type 5 with many lights: its light loop, with the whole wave (rt_device.h)
                 const float pdf_light = wave_light_pdf_q<STATS>(sc, lq, cn, lqueue);
                 if (lq.pending) {
                     finish_type5(sc, ray, lq, pdf_light);
                     ray.d = normalize_keep(ray.d);  // main.cu:361
                 }
             }
-            if (shading) {
+            if ((shading && !deferred) || finishing) {
                 if (EXTRA) {
                     volDensity = ray.volDensity;
                     volColor = ray.volColor;
@@ -451,7 +509,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             }
             RT_PROF_COUNT(cn, 7, RT_PROF_CLOCK() - pc0);
             // lanes without a path take the next ones of the wave's batch
-            bool needpath = t.cur == RT_LANE_NEW;
+            bool needpath = t.cur == RT_LANE_NEW && !finish_only;
             int x = 0, y = 0;
             unsigned long long m = __ballot(needpath);
             while (m) {
@@ -482,7 +540,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 batch_next += min(avail, (unsigned)__popcll(m));
                 m = __ballot(needpath);
             }
-            if (t.cur == RT_LANE_NEW) {
+            if (t.cur == RT_LANE_NEW && !finish_only) {
                 if (needpath) {
                     t.cur = RT_LANE_IDLE;
                 } else {  // camera sample (main.cu:178-217)
@@ -539,13 +597,13 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                 RT_PROF_COUNT(cn, 0, 1);
                 RT_PROF_LANE(cn, 1);
                 RT_PROF_LANE(cn, 14);
-                trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
+                trav_step_leaf<STATS, BIG, TLDS, FAST, FAST && COOP>(sc, t, stk, cn, n_cached);
 #pragma unroll
                 for (int k = 1; k < RT_LEAF_STEPS; k++)
-                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
+                    if (t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST, FAST && COOP>(sc, t, stk, cn, n_cached);
                 // shortcut tree over runs (1.6 triangles each): a second test before the next vote (scene.txt -1.5 %, scene2.txt -1 %;
                 // over leaves with their sub-trees, the 10M-triangle field, it loses 1 %)
-                if (FAST && RT_LEAF_STEPS == 1 && sc.short_runs && t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST>(sc, t, stk, cn, n_cached);
+                if (FAST && RT_LEAF_STEPS == 1 && sc.short_runs && t.cur >= sc.n_inner) trav_step_leaf<STATS, BIG, TLDS, FAST, FAST && COOP>(sc, t, stk, cn, n_cached);
             }
 #if RT_CYCLE_PROF == 2
             RT_PROF_COUNT(cn, 10, RT_PROF_CLOCK() - pt0);
@@ -606,10 +664,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
         }
 #endif
     if (STATS) {
-        uint32_t v[14] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights,
-                          cn.rewalks, cn.dev_wide};
+        uint32_t v[15] = {cn.paths, cn.rays, cn.inner, cn.leaf, cn.tri, cn.hits, cn.texels, cn.lights, cn.dev_inner, cn.dev_cached, cn.dev_tri, cn.dev_lights,
+                          cn.rewalks, cn.dev_wide, cn.dev_light_loops};
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
+        for (int i = 0; i < 15; i++) {
             unsigned long long s = v[i];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0 && s) atomicAdd(&stats[i], s);
@@ -1458,6 +1516,7 @@ struct HostLayout {
     bool short_runs = false, short_single = false;
     int short_cut = 0;
     int n_short = 0, short_root = RT_TRAV_DONE, short_base = 0, short_depth = 0;  // shortcut tree (rt_device.h): nodes, root item, first item of its LDS window, stack entries
+    int light_root = RT_TRAV_DONE, n_light_items = 0, light_need = 0;  // light tree (wide nodes) over the light items behind the triangles; stack entries its worst path needs
     int n_wide = 0, wide_need = 0, below_short = 0;  // wide (four-child) shortcut nodes, two items each from short_base on; stack entries their worst path needs; levels of sub-trees below the shortcut tree
     size_t light_box_off = 0, light_place_off = 0;  // floats into `lights`
     float scene_scale = 1.f, box_pad = 0.f;
@@ -1911,6 +1970,96 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
     timer.stage("sub-tree nodes merged");
+    // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once.  With enough lights for the
+    //      wave-cooperative loop (rt_device.h) the records are stored in SPATIAL order (Morton code of the centroid), so
+    //      that a group of RT_LIGHT_GROUP consecutive records is a small patch with a tight box; place[i] says where the
+    //      reference's i-th light went, and every record carries its reference index (the sum over the lights is formed
+    //      in that order, see wave_light_pdf).
+    const int nl = s->n_light_tris;
+    if (nl >= (1 << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 - 1 importance-sampled triangles (the light loop packs a light index into 24 bits)");
+    const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
+    const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 4 * RT_LIGHT_PLANES;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
+    const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
+    std::vector<float>& lights = L.lights;
+    lights.assign(light_place_off + (size_t)((std::max(nl, 1) + 3) & ~3), 0.f);
+    for (int g = 0; g < n_light_groups; g++)
+        for (int k = 0; k < 3; k++) {
+            lights[light_box_off + (size_t)g * 8 + k] = 3e38f;
+            lights[light_box_off + (size_t)g * 8 + 4 + k] = -3e38f;
+        }
+    for (int i = 0; i < nl; i++) {
+        const int off = s->light_tris[i];
+        if (off < 0 || off % RT_TRI_FLOATS || (size_t)off + RT_TRI_FLOATS > s->n_tri_floats)
+            return fail(RT_ERR_INVALID, "light triangle offset out of range");
+    }
+    std::vector<int> light_order((size_t)std::max(nl, 1));  // light_order[j] = reference index of the light stored at j
+    for (int i = 0; i < nl; i++) light_order[(size_t)i] = i;
+    if (nl >= RT_LIGHTS_COOP_MIN && !getenv("RT_LIGHTS_UNSORTED")) {
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        std::vector<float> cen((size_t)nl * 3);
+        for (int i = 0; i < nl; i++) {
+            const float* t = tris + s->light_tris[i];
+            for (int k = 0; k < 3; k++) {
+                const float cc = (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+                cen[(size_t)i * 3 + k] = cc;
+                lo[k] = std::min(lo[k], cc);
+                hi[k] = std::max(hi[k], cc);
+            }
+        }
+        auto spread = [](unsigned v) {  // 10 bits -> every third bit
+            v &= 1023u;
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        std::vector<unsigned> code((size_t)nl);
+        for (int i = 0; i < nl; i++) {
+            unsigned q[3];
+            for (int k = 0; k < 3; k++) {
+                const float w = hi[k] - lo[k];
+                const float u = w > 0.f ? (cen[(size_t)i * 3 + k] - lo[k]) / w : 0.f;
+                q[k] = (unsigned)std::min(1023.f, std::max(0.f, u * 1024.f));
+            }
+            code[(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        std::stable_sort(light_order.begin(), light_order.begin() + nl, [&](int a, int b) { return code[(size_t)a] < code[(size_t)b]; });
+    }
+    for (int j = 0; j < nl; j++) {
+        const int i = light_order[(size_t)j];
+        const float* t = tris + s->light_tris[i];
+        const H3 p1{t[0], t[1], t[2]}, p2{t[3], t[4], t[5]}, p3{t[6], t[7], t[8]};
+        const H3 e1 = hsub(p2, p1), e2 = hsub(p3, p1);
+        const H3 cr = hcross(e1, e2);
+        const H3 nrm = hnormalize(cr);
+        const float area = 0.5f * hlen(cr);
+        float Lr[24];
+        {   // bounding sphere of the triangle about its centroid, radius padded (wave_light_pdf_q drops a light only if the ray misses it)
+            const H3 cen{(p1.x + p2.x + p3.x) * (1.0f / 3.0f), (p1.y + p2.y + p3.y) * (1.0f / 3.0f), (p1.z + p2.z + p3.z) * (1.0f / 3.0f)};
+            const float r = std::max(hlen(hsub(p1, cen)), std::max(hlen(hsub(p2, cen)), hlen(hsub(p3, cen))));
+            Lr[20] = cen.x; Lr[21] = cen.y; Lr[22] = cen.z; Lr[23] = r * 1.001f + box_pad;
+        }
+        Lr[0] = p1.x; Lr[1] = p1.y; Lr[2] = p1.z; Lr[3] = e1.x; Lr[4] = e1.y; Lr[5] = e1.z;
+        Lr[6] = e2.x; Lr[7] = e2.y; Lr[8] = e2.z; Lr[9] = nrm.x; Lr[10] = nrm.y; Lr[11] = nrm.z;
+        Lr[12] = area; Lr[13] = p2.x; Lr[14] = p2.y; Lr[15] = p2.z; Lr[16] = p3.x; Lr[17] = p3.y; Lr[18] = p3.z;
+        Lr[19] = i2f(i);                                    // the light's place in the reference's list
+        for (int k = 0; k < 24; k++) lights[RT_LIGHT_F4(j, k / 4) * 4 + (size_t)(k % 4)] = Lr[k];  // plane by plane per group (rt_device.h)
+        lights[light_place_off + (size_t)i] = i2f(j);
+        float* B = &lights[light_box_off + (size_t)(j / RT_LIGHT_GROUP) * 8];
+        for (int k = 0; k < 3; k++) {
+            B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
+            B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
+        }
+    }
+    for (int g = 0; g < n_light_groups && s->n_light_tris > 0; g++) {  // pad: the culling test must never say no wrongly
+        float* B = &lights[light_box_off + (size_t)g * 8];
+        for (int k = 0; k < 3; k++) {
+            B[k] -= box_pad;
+            B[4 + k] += box_pad;
+        }
+    }
+
     // ---- SHORTCUT TREE (rt_device.h): a surface-area tree of this library's own over the reference's non-empty LEAVES
     //      (each with whatever hangs below it: its triangles or its sub-tree), padded boxes, walked with the sub-trees'
     //      slack rule.  It finds the closest hit in fewer visits than the reference's mean-split tree; a per-ray
@@ -2415,6 +2564,97 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             below_leaf = 0;          // a shortcut search no longer enters the two-child sub-trees
         }
     }
+    // ---- LIGHT TREE (rt_device.h): with enough importance-sampled triangles for it to pay, a tree of wide nodes over the light
+    //      triangles (median splits of the centroids, padded boxes) whose leaves are single LIGHT ITEMS behind the triangles of
+    //      the item stream.  The fused kernel runs reflectType5's sum over all lights (material.h:315-323) as an ALL-HITS search
+    //      of this tree with the lane's ordinary traversal steps, instead of testing the lights one by one.
+    int light_root = -1, n_light_items = 0, light_need = 0;
+    if (n_wide_top > 0 && nl >= RT_LIGHTS_COOP_MIN && !getenv("RT_NO_LIGHT_TREE")) {
+        std::vector<std::array<float, 9>> lb((size_t)nl);  // per stored light j: box (6), centroid (3)
+        for (int j = 0; j < nl; j++) {
+            const float* t = tris + s->light_tris[light_order[(size_t)j]];
+            for (int k = 0; k < 3; k++) {
+                lb[(size_t)j][(size_t)k] = std::min(t[k], std::min(t[3 + k], t[6 + k]));
+                lb[(size_t)j][(size_t)(3 + k)] = std::max(t[k], std::max(t[3 + k], t[6 + k]));
+                lb[(size_t)j][(size_t)(6 + k)] = (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
+            }
+        }
+        std::vector<int> lid((size_t)nl);
+        for (int j = 0; j < nl; j++) lid[(size_t)j] = j;
+        std::vector<ShortNode> lnodes;
+        lnodes.reserve((size_t)nl);
+        // returns the entry over lid[lo, hi) (>= 0: node in lnodes; < 0: ~(2 * place of the light's item)) and its padded box
+        auto build_light = [&](auto&& self, int lo, int hi, float* box) -> int {
+            float u[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f}, cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
+            for (int p = lo; p < hi; p++) {
+                const auto& b = lb[(size_t)lid[(size_t)p]];
+                for (int c = 0; c < 3; c++) {
+                    u[c] = std::min(u[c], b[(size_t)c]); u[3 + c] = std::max(u[3 + c], b[(size_t)(3 + c)]);
+                    cmn[c] = std::min(cmn[c], b[(size_t)(6 + c)]); cmx[c] = std::max(cmx[c], b[(size_t)(6 + c)]);
+                }
+            }
+            for (int c = 0; c < 3; c++) { box[c] = u[c] - box_pad; box[3 + c] = u[3 + c] + box_pad; }
+            if (hi - lo == 1) return ~(2 * (ntri + 1 + lid[(size_t)lo]));
+            int axis = 0;
+            for (int c = 1; c < 3; c++)
+                if (cmx[c] - cmn[c] > cmx[axis] - cmn[axis]) axis = c;
+            const int mid = lo + (hi - lo) / 2;
+            std::nth_element(lid.begin() + lo, lid.begin() + mid, lid.begin() + hi, [&](int a, int b) {
+                const float ca = lb[(size_t)a][(size_t)(6 + axis)], cb = lb[(size_t)b][(size_t)(6 + axis)];
+                return ca < cb || (ca == cb && a < b);
+            });
+            const int idx = (int)lnodes.size();
+            lnodes.push_back(ShortNode());
+            float ba[6], bb2[6];
+            const int ea = self(self, lo, mid, ba), eb = self(self, mid, hi, bb2);
+            ShortNode& nd = lnodes[(size_t)idx];
+            memcpy(nd.box[0], ba, sizeof(ba));
+            memcpy(nd.box[1], bb2, sizeof(bb2));
+            nd.e[0] = ea;
+            nd.e[1] = eb;
+            return idx;
+        };
+        float root_box[6];
+        const int lroot = build_light(build_light, 0, nl, root_box);  // (nl >= 32: an inner node)
+        auto collapse_light = [&](auto&& self, int bnode, int& need) -> int {
+            const float* kbox[4];
+            int ke[4], nk = 2;
+            kbox[0] = lnodes[(size_t)bnode].box[0]; ke[0] = lnodes[(size_t)bnode].e[0];
+            kbox[1] = lnodes[(size_t)bnode].box[1]; ke[1] = lnodes[(size_t)bnode].e[1];
+            while (nk < 4) {
+                int best = -1;
+                float ba = -1.f;
+                for (int i = 0; i < nk; i++)
+                    if (ke[i] >= 0 && half_area(kbox[i]) > ba) { ba = half_area(kbox[i]); best = i; }
+                if (best < 0) break;
+                const ShortNode& c = lnodes[(size_t)ke[best]];
+                kbox[best] = c.box[0]; ke[best] = c.e[0];
+                kbox[nk] = c.box[1]; ke[nk] = c.e[1];
+                nk++;
+            }
+            const int idx = (int)wides.size();
+            wides.push_back(WideNode());
+            WideNode nd;
+            nd.nk = nk;
+            int below = 0;
+            for (int i = 0; i < 4; i++) {
+                if (i < nk) {
+                    memcpy(nd.box[i], kbox[i], 6 * sizeof(float));
+                    int nb = 0;
+                    nd.e[i] = ke[i] >= 0 ? self(self, ke[i], nb) : ke[i];
+                    below = std::max(below, nb);
+                } else {
+                    for (int k = 0; k < 6; k++) nd.box[i][k] = 3e38f;
+                    nd.e[i] = 0;
+                }
+            }
+            wides[(size_t)idx] = nd;
+            need = nk - 1 + below;
+            return idx;
+        };
+        light_root = collapse_light(collapse_light, lroot, light_need);
+        n_light_items = nl;
+    }
     const int n_wide = (int)wides.size();
     const int n_short = (int)shorts.size();
     timer.stage("shortcut tree");
@@ -2511,8 +2751,12 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             std::nth_element(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wk.end(), wbigger);
             std::sort(wk.begin(), wk.begin() + (std::ptrdiff_t)nf, wbigger);
             wide_index.assign((size_t)n_wide, -1);
-            for (size_t k = 0; k < nf; k++) wide_index[(size_t)wk[k].second] = short_base + 2 * (int)k;
-            int next = short_base + 2 * (int)nf;
+            int next = short_base;
+            // a small light tree goes in FRONT of everything: a light query visits each of its few nodes as often as a closest-hit
+            // search visits the top of the shortcut tree, and the front of the wide range is what the LDS window holds
+            if (light_root >= 0 && n_wide - light_root <= RT_LIGHT_TREE_FRONT_MAX && !getenv("RT_LIGHT_TREE_BACK"))
+                for (int w = light_root; w < n_wide; w++) { wide_index[(size_t)w] = next; next += 2; }
+            for (size_t k = 0; k < nf; k++) { wide_index[(size_t)wk[k].second] = next; next += 2; }
             for (int w = 0; w < n_wide; w++)
                 if (wide_index[(size_t)w] < 0) { wide_index[(size_t)w] = next; next += 2; }
             rest_base = (size_t)short_base + 2 * (size_t)n_wide;
@@ -2567,7 +2811,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     RawFloats& items = L.items;
     RawFloats& cold = L.cold;
     std::vector<int>& place = L.place;
-    items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1) * 16);  // (+ one item of padding behind the last triangle)
+    items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1 + (size_t)n_light_items) * 16);  // (+ one item of padding behind the last triangle, then the light items)
     cold.size_to((size_t)std::max(ntri, 1) * 16);
     place.assign((size_t)std::max(ntri, 1), 0);
     for (int k = 0; k < 16; k++) items[((size_t)n_inner + (size_t)ntri) * 16 + (size_t)k] = 0.f;
@@ -2634,6 +2878,18 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             w[15] = i2f(2);
         }
     });
+    for (int j = 0; j < n_light_items; j++) {  // light items (rt_device.h): the light's triangle as the triangle test reads it + normal, area, reference index
+        float* h = &items[((size_t)n_inner + (size_t)ntri + 1 + (size_t)j) * 16];
+        const float* Lr[6];
+        for (int k = 0; k < 6; k++) Lr[k] = &lights[RT_LIGHT_F4(j, k) * 4];
+        h[0] = Lr[0][0]; h[1] = Lr[0][1]; h[2] = Lr[0][2];                    // p1
+        h[3] = Lr[0][3]; h[4] = Lr[1][0]; h[5] = Lr[1][1];                    // e1
+        h[6] = Lr[1][2]; h[7] = Lr[1][3]; h[8] = Lr[2][0];                    // e2
+        h[9] = i2f(1);                                                       // flags: last (and only) triangle of its leaf
+        h[10] = Lr[3][0];                                                    // area
+        h[11] = Lr[4][3];                                                    // the light's place in the reference's list (int bits)
+        h[12] = Lr[2][1]; h[13] = Lr[2][2]; h[14] = Lr[2][3]; h[15] = 0.f;   // normal
+    }
     par_ranges((size_t)n_wide, [&](int, size_t lo, size_t hi) {  // wide shortcut nodes: two items each (layout in rt_device.h)
         for (size_t j = lo; j < hi; j++) {
             const WideNode& nd = wides[j];
@@ -2676,96 +2932,6 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         d[11] = i2f((int)m.image_height);
     }
 
-    // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once.  With enough lights for the
-    //      wave-cooperative loop (rt_device.h) the records are stored in SPATIAL order (Morton code of the centroid), so
-    //      that a group of RT_LIGHT_GROUP consecutive records is a small patch with a tight box; place[i] says where the
-    //      reference's i-th light went, and every record carries its reference index (the sum over the lights is formed
-    //      in that order, see wave_light_pdf).
-    const int nl = s->n_light_tris;
-    if (nl >= (1 << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 - 1 importance-sampled triangles (the light loop packs a light index into 24 bits)");
-    const int n_light_groups = (std::max(nl, 1) + RT_LIGHT_GROUP - 1) / RT_LIGHT_GROUP;
-    const size_t light_box_off = (size_t)n_light_groups * RT_LIGHT_GROUP * 4 * RT_LIGHT_PLANES;  // padded bounds per RT_LIGHT_GROUP lights behind the records (whole groups)
-    const size_t light_place_off = light_box_off + (size_t)n_light_groups * 8;  // int place[nl] behind the boxes
-    std::vector<float>& lights = L.lights;
-    lights.assign(light_place_off + (size_t)((std::max(nl, 1) + 3) & ~3), 0.f);
-    for (int g = 0; g < n_light_groups; g++)
-        for (int k = 0; k < 3; k++) {
-            lights[light_box_off + (size_t)g * 8 + k] = 3e38f;
-            lights[light_box_off + (size_t)g * 8 + 4 + k] = -3e38f;
-        }
-    for (int i = 0; i < nl; i++) {
-        const int off = s->light_tris[i];
-        if (off < 0 || off % RT_TRI_FLOATS || (size_t)off + RT_TRI_FLOATS > s->n_tri_floats)
-            return fail(RT_ERR_INVALID, "light triangle offset out of range");
-    }
-    std::vector<int> light_order((size_t)std::max(nl, 1));  // light_order[j] = reference index of the light stored at j
-    for (int i = 0; i < nl; i++) light_order[(size_t)i] = i;
-    if (nl >= RT_LIGHTS_COOP_MIN && !getenv("RT_LIGHTS_UNSORTED")) {
-        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-        std::vector<float> cen((size_t)nl * 3);
-        for (int i = 0; i < nl; i++) {
-            const float* t = tris + s->light_tris[i];
-            for (int k = 0; k < 3; k++) {
-                const float cc = (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
-                cen[(size_t)i * 3 + k] = cc;
-                lo[k] = std::min(lo[k], cc);
-                hi[k] = std::max(hi[k], cc);
-            }
-        }
-        auto spread = [](unsigned v) {  // 10 bits -> every third bit
-            v &= 1023u;
-            v = (v | (v << 16)) & 0x030000FFu;
-            v = (v | (v << 8)) & 0x0300F00Fu;
-            v = (v | (v << 4)) & 0x030C30C3u;
-            v = (v | (v << 2)) & 0x09249249u;
-            return v;
-        };
-        std::vector<unsigned> code((size_t)nl);
-        for (int i = 0; i < nl; i++) {
-            unsigned q[3];
-            for (int k = 0; k < 3; k++) {
-                const float w = hi[k] - lo[k];
-                const float u = w > 0.f ? (cen[(size_t)i * 3 + k] - lo[k]) / w : 0.f;
-                q[k] = (unsigned)std::min(1023.f, std::max(0.f, u * 1024.f));
-            }
-            code[(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
-        }
-        std::stable_sort(light_order.begin(), light_order.begin() + nl, [&](int a, int b) { return code[(size_t)a] < code[(size_t)b]; });
-    }
-    for (int j = 0; j < nl; j++) {
-        const int i = light_order[(size_t)j];
-        const float* t = tris + s->light_tris[i];
-        const H3 p1{t[0], t[1], t[2]}, p2{t[3], t[4], t[5]}, p3{t[6], t[7], t[8]};
-        const H3 e1 = hsub(p2, p1), e2 = hsub(p3, p1);
-        const H3 cr = hcross(e1, e2);
-        const H3 nrm = hnormalize(cr);
-        const float area = 0.5f * hlen(cr);
-        float Lr[24];
-        {   // bounding sphere of the triangle about its centroid, radius padded (wave_light_pdf_q drops a light only if the ray misses it)
-            const H3 cen{(p1.x + p2.x + p3.x) * (1.0f / 3.0f), (p1.y + p2.y + p3.y) * (1.0f / 3.0f), (p1.z + p2.z + p3.z) * (1.0f / 3.0f)};
-            const float r = std::max(hlen(hsub(p1, cen)), std::max(hlen(hsub(p2, cen)), hlen(hsub(p3, cen))));
-            Lr[20] = cen.x; Lr[21] = cen.y; Lr[22] = cen.z; Lr[23] = r * 1.001f + box_pad;
-        }
-        Lr[0] = p1.x; Lr[1] = p1.y; Lr[2] = p1.z; Lr[3] = e1.x; Lr[4] = e1.y; Lr[5] = e1.z;
-        Lr[6] = e2.x; Lr[7] = e2.y; Lr[8] = e2.z; Lr[9] = nrm.x; Lr[10] = nrm.y; Lr[11] = nrm.z;
-        Lr[12] = area; Lr[13] = p2.x; Lr[14] = p2.y; Lr[15] = p2.z; Lr[16] = p3.x; Lr[17] = p3.y; Lr[18] = p3.z;
-        Lr[19] = i2f(i);                                    // the light's place in the reference's list
-        for (int k = 0; k < 24; k++) lights[RT_LIGHT_F4(j, k / 4) * 4 + (size_t)(k % 4)] = Lr[k];  // plane by plane per group (rt_device.h)
-        lights[light_place_off + (size_t)i] = i2f(j);
-        float* B = &lights[light_box_off + (size_t)(j / RT_LIGHT_GROUP) * 8];
-        for (int k = 0; k < 3; k++) {
-            B[k] = std::min(B[k], std::min(t[k], std::min(t[3 + k], t[6 + k])));
-            B[4 + k] = std::max(B[4 + k], std::max(t[k], std::max(t[3 + k], t[6 + k])));
-        }
-    }
-    for (int g = 0; g < n_light_groups && s->n_light_tris > 0; g++) {  // pad: the culling test must never say no wrongly
-        float* B = &lights[light_box_off + (size_t)g * 8];
-        for (int k = 0; k < 3; k++) {
-            B[k] -= box_pad;
-            B[4 + k] += box_pad;
-        }
-    }
-
     // ---- spheres
     std::vector<float>& spheres = L.spheres;
     spheres.assign((size_t)std::max(s->n_spheres, 1) * 8, 0.f);
@@ -2785,6 +2951,9 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     L.n_wide = n_wide;
     L.short_root = wide_root >= 0 ? wide_index[(size_t)wide_root] : (short_root >= 0 ? short_index[(size_t)short_root] : RT_TRAV_DONE);
     L.wide_need = wide_need;
+    L.light_root = light_root >= 0 ? wide_index[(size_t)light_root] : RT_TRAV_DONE;
+    L.n_light_items = n_light_items;
+    L.light_need = light_need;
     L.below_short = below_leaf;
     L.short_base = short_base;
     L.short_runs = short_runs;
@@ -2830,6 +2999,8 @@ static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout&
     sc.short_base = L.short_base;
     sc.short_runs = L.short_runs ? 1 : 0;
     sc.short_single = L.short_single ? 1 : 0;
+    sc.light_root = L.light_root;
+    sc.n_light_items = L.n_light_items;
     sc.wide_lo = L.short_base;
     sc.wide_n = 2 * L.n_wide;
     // (the stack has max(depth, short_depth) entries: trace_cfg; the sub-trees below the shortcut tree push one entry per level)
@@ -2915,6 +3086,9 @@ int rt_layout_get_v2(const rt_layout* h, rt_layout_info* info_out, size_t info_s
         info->n_wide = h->L.n_wide;
         info->wide_need = h->L.wide_need;
         info->wide_sp_max = std::max(h->L.depth, h->L.short_depth) - h->L.below_short - 3;
+        info->light_root = h->L.light_root;
+        info->n_light_items = h->L.n_light_items;
+        info->light_need = h->L.light_need;
         memcpy(info_out, &full, std::min(info_size, sizeof(full)));
     }
     if (items) *items = h->L.items.data();
@@ -3019,7 +3193,7 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)(c->sc.n_inner - (fast ? c->sc.short_base : 0)));
     // a scene whose whole item stream fits (the Cornell box): the triangles too, so that a leaf step reads the LDS
     // instead of L1 (path-parallel kernel only: its leaf step knows)
-    const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris;
+    const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris + (c->sc.n_light_items ? 1 + (size_t)c->sc.n_light_items : 0);  // (the light items stand behind the triangles)
     if (with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
     t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
     t.grid = c->num_cus;
@@ -3163,7 +3337,10 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
                       !((P.flags & RT_F_SPHERES) && c->sc.n_spheres > 0);
     // the shortcut tree (rt_device.h) unless the call asks for the reference's walk, or counts it (RT_F_STATS)
     const bool fast = c->sc.short_root >= 0 && !pool && !(P.flags & (RT_F_REFWALK | RT_F_VOLUME | RT_F_RAYMARCH)) && (P.flags & RT_F_BVH) &&
-                      (!want_stats || (P.flags & RT_F_SHORTCUT_STATS)) && !getenv("RT_REFWALK");
+                      (!want_stats || (P.flags & RT_F_SHORTCUT_STATS)) && !getenv("RT_REFWALK") &&
+                      // (many lights but no light tree -- the two-child shortcut form of the experiments: the shortcut kernel would run the
+                      // plain loop over all lights per lane; the reference-walk kernel has the wave-cooperative loop)
+                      !(c->sc.n_lights >= RT_LIGHTS_COOP_MIN && c->sc.light_root < 0);
     const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true, fast);
     int rc = set_mega_lds(c, tc);
     if (rc != RT_OK) return rc;
@@ -3398,7 +3575,7 @@ int render_impl(rt_context* c, const rt_render_params* p, rt_render_stats* stats
 #endif
             stats->paths = h[0]; stats->rays = h[1]; stats->inner_visits = h[2]; stats->leaf_visits = h[3];
             stats->tri_tests = h[4]; stats->hits = h[5]; stats->texel_fetches = h[6]; stats->light_tests = h[7];
-            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11]; stats->shortcut_rewalks = h[12]; stats->dev_wide_visits = h[13];
+            stats->dev_inner_visits = h[8]; stats->dev_lds_inner_visits = h[9]; stats->dev_tri_tests = h[10]; stats->dev_light_tests = h[11]; stats->shortcut_rewalks = h[12]; stats->dev_wide_visits = h[13]; stats->dev_light_loops = h[14];
         }
     }
     return RT_OK;

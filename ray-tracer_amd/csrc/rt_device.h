@@ -91,6 +91,8 @@ struct Scene {
     int short_base;          // first item of the window [short_base, short_base + n_cached) the shortcut walk caches in LDS
     int short_single;        // ... over single triangles (tiny scenes): a shortcut search leaves a leaf after ONE test, whatever its 'last' flag
     int short_runs;          // the shortcut tree stands over the runs of the item stream (short ones: two triangle tests per leaf iteration pay)
+    int light_root;          // root (wide node) of the LIGHT TREE over the light items, RT_TRAV_DONE without one
+    int n_light_items;       // light items behind the triangles: items [n_inner + n_tris + 1, + n_light_items)
     int wide_lo, wide_n;     // WIDE shortcut nodes (four children, two items each): items [wide_lo, wide_lo + wide_n); wide_n = 0: binary shortcut nodes
     int wide_sp_max;         // a wide visit needs room for three pushes (and the sub-trees below the shortcut tree for theirs): with more than this
                              // many entries on its stack the search gives up and the ray walks the reference's tree
@@ -240,12 +242,13 @@ struct Counters {
     uint32_t rewalks;  // shortcut searches that were not certified and walked the reference's tree again
     uint32_t dev_inner, dev_cached, dev_tri, dev_lights;  // (dev_lights: light-triangle pdf tests really run, after the group culling)
     uint32_t dev_wide;  // visits of wide shortcut nodes (each also counts two items in dev_inner / dev_cached)
+    uint32_t dev_light_loops;  // light queries the light tree did not serve: summed by the loop over every light
 #ifdef RT_CYCLE_PROF  // instrumented experiment builds only (tools/ab_build.sh): where do a wave's cycles go?
     unsigned long long prof[16];  // (8..15: lane census per iteration kind, rt_render_paths_kernel)   0 trav wave-iterations, 1 trav lane-steps, 2 trav cycles, 3 vertex passes, 4 vertex lanes, 5 vertex cycles, 6 loop cycles
 #endif
     __device__ __forceinline__ void clear() {
         paths = rays = inner = leaf = tri = hits = texels = lights = 0;
-        dev_inner = dev_cached = dev_tri = dev_lights = rewalks = dev_wide = 0;
+        dev_inner = dev_cached = dev_tri = dev_lights = rewalks = dev_wide = dev_light_loops = 0;
 #ifdef RT_CYCLE_PROF
         for (int i = 0; i < 16; i++) prof[i] = 0;
 #endif
@@ -614,15 +617,38 @@ __device__ __forceinline__ bool tie_replaces(const Scene& sc, int heldPlace, flo
 }
 
 // One triangle test of the current leaf (main.cu:249-264) on the fetched item.
-template <bool STATS, bool SUB, bool FAST = false>
+// LQ: the lane may be running a LIGHT QUERY (Trav::bestLeaf <= RT_LQ_RUNNING, see light_query_begin): the item is then a light
+// item, and a hit adds the light's pdf term (ImportanceTri::pdf_value, importanceTri.h:67-76, over the number of lights) to
+// the lane's sum instead of competing for the closest hit.
+#define RT_LQ_RUNNING (-3)
+#define RT_LQ_GAVE_UP (-4)
+template <bool STATS, bool SUB, bool FAST = false, bool LQ = false>
 __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const int* stk, Counters& cn, int item, float4 q0, float4 q1,
-                                               float4 q2) {
+                                               float4 q2, float4 q3 = make_float4(0.f, 0.f, 0.f, 0.f)) {
     const int flags = __float_as_int(q2.y);
-    if (STATS) { cn.tri += !(flags & 4); cn.leaf += (flags >> 1) & 1; cn.dev_tri++; }
+    const bool lq = LQ && t.bestLeaf <= RT_LQ_RUNNING;
+    if (STATS) {
+        if (lq) cn.dev_lights++;
+        else { cn.tri += !(flags & 4); cn.leaf += (flags >> 1) & 1; cn.dev_tri++; }
+    }
     float ht;
     const f3 o = t.o();
     if (ray_triangle_t(o, t.d, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), ht)) {
         const f3 pos = o + t.d * ht;
+        if (lq) {  // itri_pdf behind its ray_triangle: q2.z = the light's area, the fourth piece of the item (q3, fetched with the others
+                   // where light queries run: a fetch of its own here would be one more memory latency for the whole wave) its normal.
+                   // (Noting the hit and forming the term in the finishing pass was measured: slower, 58.1 vs 54.5 ms on scene2_is.txt.)
+            const f3 to = pos - o;
+            const float distance_squared = len2(to);
+            const float cos_theta = fabsf(dot(normalize(to), mk(q3.x, q3.y, q3.z)));
+            const float term = distance_squared / (cos_theta * q2.z) / (float)sc.n_lights;
+            if (term != 0.0f) {  // (0 + a) + b: up to two nonzero terms commute; the third sends the query to the loop over all lights
+                t.minD2 += term;
+                t.hitTri++;
+            }
+            trav_pop(t, stk);
+            return;
+        }
         const float nd = len2(pos - o);
         if (nd < t.minD2 || (SUB && nd == t.minD2 && tie_replaces(sc, t.hitTri, q2, false))) {
             if (FAST && __float_as_int(q2.z) != t.bestLeaf) {  // the hit it replaces (1e12 before the first) is from another leaf: a rival
@@ -748,7 +774,7 @@ __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* st
     }
     if (STATS) { cn.dev_inner += 2; cn.dev_wide++; }
     if (t.sp > sc.wide_sp_max) {  // no room for three more entries: give up, the reference's walk decides (short_certified)
-        t.bestLeaf = -2;
+        t.bestLeaf = t.bestLeaf <= RT_LQ_RUNNING ? RT_LQ_GAVE_UP : -2;  // (a light query: its sum is then formed by the loop over all lights)
         t.cur = RT_TRAV_DONE;
         return;
     }
@@ -779,7 +805,7 @@ __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* st
 }
 
 // TLDS: a scene so small that its WHOLE item stream sits in the LDS cache (n_cached = inner items + triangles).
-template <bool STATS, bool SUB, bool TLDS = false, bool FAST = false>
+template <bool STATS, bool SUB, bool TLDS = false, bool FAST = false, bool LQ = false>
 __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const int* stk, Counters& cn, int n_cached = 0) {  // a triangle or RT_TRAV_EMPTY
     if (t.cur == RT_TRAV_EMPTY) {
         if (STATS) cn.leaf++;
@@ -788,19 +814,23 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
     }
     if (TLDS) {
         float4 q0, q1, q2, q3;
-        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);  // (the fourth piece is padding: its read is dropped)
-        visit_triangle<STATS, SUB, FAST>(sc, t, stk, cn, t.cur, q0, q1, q2);
+        load_cached_item(t.cur, n_cached, q0, q1, q2, q3);  // (the fourth piece is padding unless light queries run: its read is dropped)
+        visit_triangle<STATS, SUB, FAST, LQ>(sc, t, stk, cn, t.cur, q0, q1, q2, q3);
         return;
     }
     const float4* w = sc.items + 4 * (size_t)t.cur;
-    float4 q0 = w[0], q1 = w[1], q2 = w[2];
+    float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LQ) {
+        q3 = w[3];
+        asm volatile("" : "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+    }
 #if RT_TRI_LOAD_PIN
     // three aligned 16-byte loads issued together: left alone, the compiler sinks the load of v0 behind the
     // determinant test (a second memory latency in most steps) and fetches the rest as unaligned pieces
     asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y),
                  "+v"(q2.z), "+v"(q2.w));
 #endif
-    visit_triangle<STATS, SUB, FAST>(sc, t, stk, cn, t.cur, q0, q1, q2);
+    visit_triangle<STATS, SUB, FAST, LQ>(sc, t, stk, cn, t.cur, q0, q1, q2, q3);
 }
 
 // Shortcut walk (see SHORTCUT TREE above).  short_begin: after trav_begin has tested the reference's root box, send the
@@ -830,6 +860,38 @@ __device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t) 
     const float bd = aabb_distance(t.o(), t.inv(), mk(mn.x, mn.y, mn.z), mk(mx.x, mx.y, mx.z));
     const float bd2 = bd * bd;
     return bd2 < t.rival && t.minD2 < t.rival && bd2 <= t.minD2 * 1.00001f + 0.5f * t.slack;
+}
+
+// LIGHT QUERY.  reflectType5 sums ImportanceTri::pdf_value over EVERY importance-sampled triangle for the sampled direction
+// (material.h:315-323); the terms that are not +0 belong to the lights the ray (hitPos, outgoing) HITS.  With a light tree
+// (Scene::light_root) the lane finds them as an all-hits search through its ordinary traversal steps: nothing is pruned by
+// distance, a leaf is one light item, a hit adds its term (visit_triangle).  The query's state rides in fields a closest-hit
+// search does not need meanwhile: minD2 = the sum so far, hitTri = nonzero terms so far, hitT = pdf_cos, bestLeaf = the mode.
+// False: this ray cannot use the tree (same conditions as short_begin) -- the caller runs the loop over all lights instead.
+__device__ __forceinline__ bool light_query_begin(const Scene& sc, Trav& t, f3 o, f3 d, float pdf_cos) {
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool ok = fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY && fabsf(o.x * inv.x) < INFINITY &&
+                    fabsf(o.y * inv.y) < INFINITY && fabsf(o.z * inv.z) < INFINITY &&
+                    fmaxf(fabsf(o.x), fmaxf(fabsf(o.y), fabsf(o.z))) <= sc.cull_far;
+    if (!ok) return false;
+    t.oxy = (v2f){o.x, o.y};
+    t.oz = o.z;
+    t.d = d;
+    t.ixy = (v2f){inv.x, inv.y};
+    t.iz = inv.z;
+    t.axis_parallel = false;
+    t.sgx = inv.x < 0.0f ? 80 : 0;
+    t.sgy = inv.y < 0.0f ? 80 : 0;
+    t.sgz = inv.z < 0.0f ? 80 : 0;
+    t.sp = 0;
+    t.limT = 3e38f;   // all hits: no child is too far
+    t.rival = -1.0f;  // (not a shortcut search: nothing to certify)
+    t.bestLeaf = RT_LQ_RUNNING;
+    t.minD2 = 0.0f;
+    t.hitTri = 0;
+    t.hitT = pdf_cos;
+    t.cur = sc.light_root;
+    return true;
 }
 
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -1199,6 +1261,21 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.emission = mk(1.0f, 0.0f, 1.0f);
             return true;
     }
+}
+
+// The loop of material.h:315-323 as the reference runs it: every light, in list order.
+template <bool STATS>
+__device__ __forceinline__ float light_pdf_loop(const Scene& sc, f3 hitPos, f3 outgoing, Counters& cn) {
+    float pdf_light = 0.0f;
+    for (int i = 0; i < sc.n_lights; i++) {
+        const int pj = sc.light_place[i];
+        const float4 l0 = sc.lights[RT_LIGHT_F4(pj, 0)], l1 = sc.lights[RT_LIGHT_F4(pj, 1)], l2 = sc.lights[RT_LIGHT_F4(pj, 2)],
+                     l3 = sc.lights[RT_LIGHT_F4(pj, 3)];
+        if (STATS) { cn.lights++; cn.dev_lights++; }
+        pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w), l3.x) /
+                     (float)sc.n_lights;
+    }
+    return pdf_light;
 }
 
 // The tail of reflectType5 behind the light loop (material.h:324-335).
