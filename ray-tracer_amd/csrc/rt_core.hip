@@ -1522,7 +1522,58 @@ struct HostLayout {
     float scene_scale = 1.f, box_pad = 0.f;
 };
 
-int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, UploadTimer& timer) {
+// What does not depend on the layout -- the cold triangle data (the reference's order) and the texture pool, 45 % of a big scene's
+// bytes -- is formed and copied to the device by a thread of its own WHILE build_layout runs (rt_upload_scene only).
+struct EarlyUpload {
+    rt_context* c = nullptr;
+    std::thread th;
+    bool started = false;
+    int rc = RT_OK;
+    std::string err;
+    void* d_cold = nullptr;
+    void* d_tex = nullptr;
+    void start(const rt_scene_desc* s, const float* tris, int ntri, RawFloats* cold) {
+        started = true;
+        th = std::thread([this, s, tris, ntri, cold] {
+            auto fail = [&](const char* what, hipError_t e) { rc = RT_ERR_DEVICE; err = std::string(what) + ": " + hipGetErrorString(e); };
+            hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) return fail("hipSetDevice", e);
+            const size_t tex_bytes = s->n_tex_floats * 4;
+            if ((e = hipMalloc(&d_tex, tex_bytes ? tex_bytes : 16)) != hipSuccess) return fail("hipMalloc(textures)", e);
+            if (tex_bytes && (e = hipMemcpy(d_tex, s->textures, tex_bytes, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(textures)", e);
+            cold->size_to((size_t)std::max(ntri, 1) * 16);
+            if (ntri == 0)
+                for (int k = 0; k < 16; k++) (*cold)[(size_t)k] = 0.f;
+            const int nt = ntri >= (1 << 16) ? 4 : 1;
+            std::vector<std::thread> w;
+            auto fill = [&](int wi) {
+                for (size_t p = (size_t)ntri * (size_t)wi / (size_t)nt; p < (size_t)ntri * (size_t)(wi + 1) / (size_t)nt; p++) {
+                    const float* u = tris + p * RT_TRI_FLOATS;
+                    float* cd = &(*cold)[p * 16];
+                    for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
+                    cd[15] = i2f(static_cast<int>(u[24]));  // main.cu:353
+                }
+            };
+            for (int wi = 1; wi < nt; wi++) w.emplace_back(fill, wi);
+            fill(0);
+            for (auto& t : w) t.join();
+            if ((e = hipMalloc(&d_cold, cold->size() * 4)) != hipSuccess) return fail("hipMalloc(cold data)", e);
+            if ((e = hipMemcpy(d_cold, cold->data(), cold->size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(cold data)", e);
+        });
+    }
+    int finish() {
+        if (started && th.joinable()) th.join();
+        return rc;
+    }
+    void discard() {  // the upload did not go through: give the early copies back
+        finish();
+        if (d_cold) (void)hipFree(d_cold);
+        if (d_tex) (void)hipFree(d_tex);
+        d_cold = d_tex = nullptr;
+    }
+};
+
+int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, UploadTimer& timer, EarlyUpload* early = nullptr) {
     auto fail = [&](int code, const std::string& msg) { err = msg; return code; };
     if (!s) return fail(RT_ERR_INVALID, "null scene");
     if (s->n_tri_floats % RT_TRI_FLOATS) return fail(RT_ERR_INVALID, "n_tri_floats is not a multiple of 25");
@@ -1568,6 +1619,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     if (max_depth > RT_STACK_ENTRIES)
         return fail(RT_ERR_LIMIT, "BVH depth " + std::to_string(max_depth) + " exceeds the traversal stack (" +
                                            std::to_string(RT_STACK_ENTRIES) + ")");
+    if (early) early->start(s, tris, ntri, &L.cold);
     timer.stage("checks, depths");
     // ---- leaf sub-trees (rt_device.h): a leaf with at least big_leaf triangles may get a tree of its own where the
     //      surface-area estimate says it pays (build_sub below): padded boxes, the triangles reordered inside the
@@ -1582,7 +1634,10 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     if (const char* e = getenv("RT_SUB_SWEEP_MAX")) sweep_max = std::max(2, atoi(e));  // experiments only
     int sub_min_tris = RT_SUB_MIN_TRIS;
     if (const char* e = getenv("RT_SUB_MIN_TRIS")) sub_min_tris = atoi(e);             // tests: sub-trees in small scenes too
-    struct SubNode { float box[2][6]; int e[2]; int cnt; };  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
+    struct SubNode {  // e >= 0: sub node, e < 0: ~(place of a sub-leaf's first triangle)
+        float box[2][6]; int e[2]; int cnt;
+        SubNode() {}  // (no zero-fill when the merged vector of millions of them is sized: every element is written)
+    };
     std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
     std::vector<int> leaf_end((size_t)std::max(ntri, 1), 0), sub_root((size_t)std::max(nn, 1), -1);
     std::vector<int> leaf_node((size_t)std::max(ntri, 1), 0);  // place -> the reference leaf (node index) that holds it
@@ -2437,10 +2492,14 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     // ---- WIDE SHORTCUT NODES (rt_device.h): the binary tree collapsed into nodes of up to four children -- the child with
     //      the biggest box is replaced by its own two children until there are four (or only leaves are left).  The
     //      binary nodes are then not emitted.  RT_SHORT_BINARY keeps them (experiments, tests of the two-child form).
-    struct WideNode { float box[4][6]; int e[4]; int nk; };  // e >= 0: wide node; e < 0: ~(ShortPrim::node of what hangs there); slots >= nk unused
+    struct WideNode {  // e >= 0: wide node; e < 0: ~(ShortPrim::node of what hangs there); slots >= nk unused
+        float box[4][6]; int e[4]; int nk;
+        WideNode() {}  // (no zero-fill when a vector of millions of them is sized: whoever sizes it writes every element)
+    };
     std::vector<WideNode> wides;
     int wide_root = -1, wide_need = 0;  // (stack entries a search of the wide tree can need: sum of (children - 1) down the worst path)
     int n_wide_top = 0;                 // wide nodes of the shortcut tree proper (the others: wide forms of sub-tree parts, huge scenes)
+    timer.stage("shortcut tree: two-child build");
     if (short_root >= 0 && !getenv("RT_SHORT_BINARY")) {
         wides.reserve(shorts.size() / 2 + 1);
         auto collapse = [&](auto&& self, int bnode, int& need) -> int {
@@ -2482,6 +2541,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         wide_root = collapse(collapse, short_root, wide_need);
         shorts.clear();
         n_wide_top = (int)wides.size();
+        timer.stage("shortcut tree: collapse to wide nodes");
         if (!short_runs && !getenv("RT_WIDE_TOP_ONLY")) {
             // The shortcut tree stands over a frontier of the leaves' sub-trees (huge scenes): what hangs below the frontier is
             // collapsed into wide nodes as well -- a second, four-child form of those parts of the sub-trees, for the shortcut walk
@@ -2532,6 +2592,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             std::vector<std::vector<WideNode>> loc((size_t)n_workers_max);
             std::vector<int> task_root(tasks.size(), 0), need_max((size_t)n_workers_max, 0), task_worker(tasks.size(), 0);
             const int nw = par_ranges(tasks.size(), [&](int wi, size_t lo, size_t hi) {
+                // (two-child nodes collapse to about 0.45 wide nodes each; the tasks are spread evenly: no regrowth in the common case)
+                loc[(size_t)wi].reserve((size_t)((double)subs.size() * 0.5 * (double)(hi - lo) / (double)std::max<size_t>(tasks.size(), 1)) + 64);
                 for (size_t k = lo; k < hi; k++) {
                     int need = 0;
                     task_root[k] = collapse_sub(collapse_sub, loc[(size_t)wi], tasks[k].sub, need);
@@ -2539,6 +2601,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     need_max[(size_t)wi] = std::max(need_max[(size_t)wi], need);
                 }
             });
+            timer.stage("shortcut tree: wide forms of the sub-tree parts (threads)");
             std::vector<size_t> off((size_t)nw + 1, (size_t)n_wide_top);
             for (int wi = 0; wi < nw; wi++) off[(size_t)wi + 1] = off[(size_t)wi] + loc[(size_t)wi].size();
             wides.resize(off[(size_t)nw]);
@@ -2560,6 +2623,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             int sub_need = 0;
             for (size_t k = 0; k < tasks.size(); k++) wides[(size_t)tasks[k].w].e[tasks[k].i] = (int)off[(size_t)task_worker[k]] + task_root[k];
             for (int wi = 0; wi < nw; wi++) sub_need = std::max(sub_need, need_max[(size_t)wi]);
+            timer.stage("shortcut tree: wide forms merged");
             wide_need += sub_need;   // (an upper bound: the deepest frontier part below the deepest path of the shortcut tree)
             below_leaf = 0;          // a shortcut search no longer enters the two-child sub-trees
         }
@@ -2812,10 +2876,10 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     RawFloats& cold = L.cold;
     std::vector<int>& place = L.place;
     items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1 + (size_t)n_light_items) * 16);  // (+ one item of padding behind the last triangle, then the light items)
-    cold.size_to((size_t)std::max(ntri, 1) * 16);
+    if (!early) cold.size_to((size_t)std::max(ntri, 1) * 16);  // (early: the other thread sizes, fills and uploads it)
     place.assign((size_t)std::max(ntri, 1), 0);
     for (int k = 0; k < 16; k++) items[((size_t)n_inner + (size_t)ntri) * 16 + (size_t)k] = 0.f;
-    if (ntri == 0)
+    if (ntri == 0 && !early)
         for (int k = 0; k < 16; k++) cold[(size_t)k] = 0.f;
     par_ranges((size_t)ntri, [&](int, size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++) {
@@ -2829,6 +2893,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             h[9] = i2f((int)tflags[p]); h[10] = i2f(leaf_end[p]); h[11] = i2f(tri);
             h[12] = i2f(leaf_node[p]);
             h[13] = h[14] = h[15] = 0.f;
+            if (early) continue;
             const float* u = tris + p * RT_TRI_FLOATS;                    // cold data stays in the reference's order
             float* cd = &cold[p * 16];
             for (int k = 0; k < 15; k++) cd[k] = u[9 + k];
@@ -2977,7 +3042,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
 static int prime_trace_kernels(rt_context* c);
 // The device half of rt_upload_scene: allocations and copies of a layout that is built (rt_comm_upload_scene builds it
 // once for all its ranks).
-static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout& L, UploadTimer& timer) {
+static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout& L, UploadTimer& timer, EarlyUpload* early = nullptr) {
     int rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const int nn = s->n_nodes;
@@ -2985,11 +3050,15 @@ static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout&
     if ((rc = upload_buf(c, &c->d_place, L.place.data(), L.place.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_refboxes, L.ref_boxes.data(), L.ref_boxes.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_items, L.items.data(), L.items.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_cold, L.cold.data(), L.cold.size() * 4)) != RT_OK) return rc;
+    if (early) {  // (copied while the layout was built)
+        c->d_cold = early->d_cold;
+        c->d_tex = early->d_tex;
+        early->d_cold = early->d_tex = nullptr;
+    } else if ((rc = upload_buf(c, &c->d_cold, L.cold.data(), L.cold.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_mats, L.mats.data(), L.mats.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_lights, L.lights.data(), L.lights.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_spheres, L.spheres.data(), L.spheres.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_tex, s->textures, s->n_tex_floats * 4)) != RT_OK) return rc;
+    if (!early && (rc = upload_buf(c, &c->d_tex, s->textures, s->n_tex_floats * 4)) != RT_OK) return rc;
 
     Scene& sc = c->sc;
     sc.items = (const float4*)c->d_items;
@@ -3038,9 +3107,22 @@ int rt_upload_scene(rt_context* c, const rt_scene_desc* s) {
     UploadTimer timer;
     HostLayout L;
     std::string err;
-    const int rc = build_layout(s, L, err, timer);
-    if (rc != RT_OK) return set_err(c, rc, err);
-    return upload_built(c, s, L, timer);
+    EarlyUpload early;
+    early.c = c;
+    int rc = build_layout(s, L, err, timer, getenv("RT_NO_EARLY_UPLOAD") ? nullptr : &early);
+    if (rc != RT_OK) {
+        early.discard();
+        return set_err(c, rc, err);
+    }
+    if (early.started && (rc = early.finish()) != RT_OK) {
+        const std::string msg = early.err;
+        early.discard();
+        return set_err(c, rc, msg);
+    }
+    timer.stage("early copies joined (cold data, textures)");
+    rc = upload_built(c, s, L, timer, early.started ? &early : nullptr);
+    if (rc != RT_OK) early.discard();
+    return rc;
 }
 
 // Host-side inspection of the device layout (include/rt.h): no device needed.

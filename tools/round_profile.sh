@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: the round's evidence for ONE workload -- counter passes, rocprofv3 kernel stats of the bench command, then
-# the bench line that reads them.    usage: tools/round_profile.sh <config c2|c3|c3is|c4|c5> [tag, default r02] [bench args]
+# the bench line that reads them.    usage: tools/round_profile.sh <config c2|c3|c3is|c4|c5> [tag, default r03] [bench args]
 # Writes profiles/<tag>_pmc_<workload>.json, profiles/<tag>_kernel_stats_<config>.csv, profiles/<tag>_bench_<config>.json.
-cfg=${1:-c2}; tag=${2:-r02}; shift 2 2>/dev/null
+cfg=${1:-c2}; tag=${2:-r03}; shift 2 2>/dev/null
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $root
 A="--config $cfg --steps 2 --warmup 0 $*"
