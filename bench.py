@@ -96,8 +96,8 @@ def stored_pmc(key):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: c2 40 -- a timed region of about a second --, c3 / c3is / c4 10, c5 5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: c2 5, the others 2)")
     ap.add_argument("--config", choices=sorted(PRESETS), default="c2")
     ap.add_argument("--scene", default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -111,7 +111,7 @@ def parse_args():
                     help="fused kernel: shortcut = the library's surface-area tree over the reference's leaves first, the reference's own "
                          "tree for the rays whose result is not certified (default; same sums bit for bit); reference = RT_F_REFWALK")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--synth-instances", type=int, default=None, help="use the synthetic instanced field instead of --scene")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="sah = the NON-PARITY fast mode (binned-SAH tree, depth <= 24, leaves <= 2), reported separately")
@@ -122,6 +122,10 @@ def parse_args():
     for k, v in pre.items():
         if getattr(args, k, None) is None:
             setattr(args, k, v)
+    if args.steps is None:
+        args.steps = {"c2": 40, "c5": 5}.get(args.config, 10)
+    if args.warmup is None:
+        args.warmup = 5 if args.config == "c2" else 2
     if args.scene is None:
         args.scene = "scene.txt"
     if args.synth_instances is None:
@@ -405,7 +409,9 @@ def cpu_baseline(rt, scene, args):
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(usable, int(os.environ.get("OMP_NUM_THREADS", str(usable)))))
     w, h, spp = args.width, args.height, min(args.cpu_spp, args.spp)
-    if args.config in ("c3", "c3is", "c4"):   # heavier per ray than c2: quarter frame, 4 spp
+    if args.config in ("c3", "c3is"):         # heavier per ray than c2: quarter frame, 16 spp
+        w, h, spp = w // 2, h // 2, min(16, spp)
+    elif args.config == "c4":                 # 10M triangles, 150 per leaf in the oracle's walk: quarter frame, 4 spp
         w, h, spp = w // 2, h // 2, min(4, spp)
     p = rt.default_params(scene.camera, spp=spp, width=w, height=h, max_bounces=args.bounces, flags=rt.F_DEFAULT | rt.F_STATS)
     t0 = time.perf_counter()

@@ -379,9 +379,10 @@ class LayoutInfo(C.Structure):  # rt_layout_info, include/rt.h
                 ("light_root", C.c_int32), ("n_light_items", C.c_int32), ("light_need", C.c_int32)]
 
 
-def device_layout(scene: "Scene"):
+def device_layout(scene: "Scene", light_items: bool = False):
     """The layout rt_upload_scene would copy to the GPU, built on the host (rt_layout_create; no device needed):
-    (LayoutInfo, items [n_items, 16] float32, places [n_tris] int32), copies owned by the caller."""
+    (LayoutInfo, items [n_items, 16] float32, places [n_tris] int32), copies owned by the caller.  light_items: the
+    items include what stands behind the triangles (one item of padding, then info.n_light_items light items)."""
     L = core_lib()
     h = C.c_void_p()
     err = C.create_string_buffer(256)
@@ -392,7 +393,7 @@ def device_layout(scene: "Scene"):
         info = LayoutInfo()
         items_p, places_p = _fp(), _ip()
         L.rt_layout_get_v2(h, C.byref(info), C.sizeof(info), C.byref(items_p), C.byref(places_p))
-        n_items = info.n_inner + info.n_tris
+        n_items = info.n_inner + info.n_tris + ((1 + info.n_light_items) if (light_items and info.n_light_items) else 0)
         items = np.ctypeslib.as_array(items_p, shape=(max(n_items, 1), 16))[:n_items].copy()
         places = np.ctypeslib.as_array(places_p, shape=(max(info.n_tris, 1),))[:info.n_tris].copy()
     finally:

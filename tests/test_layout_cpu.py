@@ -507,3 +507,49 @@ def test_layout_errors_are_reported(rt):
             rt.device_layout(sc)
     finally:
         sc.desc.n_tri_floats += 1
+
+
+def test_light_tree_holds_every_light_once(rt, scenes):
+    """The LIGHT TREE of a scene with enough importance-sampled triangles (csrc/rt_device.h): wide nodes inside the range of the
+    wide shortcut nodes whose leaves are the light items behind the triangles -- every light exactly once, each item the
+    light's triangle as the triangle test reads it (v0, e1, e2) with its normal, area and place in the reference's list, and
+    every child box holding the triangles below it with the padding."""
+    sc = scenes("scene2_is.txt")
+    info, items, _ = rt.device_layout(sc, light_items=True)
+    lights = sc.lights()
+    n = len(lights)
+    assert n == 960 == info.n_light_items and info.light_root >= 0
+    lo = info.short_base
+    assert lo <= info.light_root < lo + 2 * info.n_wide and (info.light_root - lo) % 2 == 0
+    first = info.n_inner + info.n_tris + 1
+    assert items.shape[0] == first + n and not items[first - 1].any()
+    tris = sc.tris()
+    seen = np.zeros(n, int)
+
+    def walk(entry):
+        if entry >= info.n_inner:
+            j = entry - first
+            assert 0 <= j < n
+            w = items[entry]
+            ref = int(as_int(w[11:12])[0])                                 # the light's place in the reference's list
+            seen[ref] += 1
+            rec = tris[lights[ref] // 25]
+            v0, v1, v2 = rec[0:3], rec[3:6], rec[6:9]
+            assert np.array_equal(w[0:3], v0) and np.array_equal(w[3:6], v1 - v0) and np.array_equal(w[6:9], v2 - v0)
+            assert int(as_int(w[9:10])[0]) == 1                             # one light per leaf: "last" flag
+            cr = np.cross((v1 - v0).astype(np.float64), (v2 - v0).astype(np.float64))
+            assert abs(w[10] - 0.5 * np.linalg.norm(cr)) <= 1e-5 * w[10]    # area
+            assert np.allclose(w[12:15], cr / np.linalg.norm(cr), atol=1e-5)
+            return [np.stack([v0, v1, v2])]
+        below = []
+        for e, box in wide_children(items, info, entry):
+            got = walk(e)
+            pts = np.concatenate(got)
+            assert (box[:3] <= pts.min(0) - 0.5 * info.box_pad).all() and (box[3:] >= pts.max(0) + 0.5 * info.box_pad).all()
+            below += got
+        return below
+
+    walk(info.light_root)
+    assert (seen == 1).all()
+    # without enough lights for it to pay there is no light tree
+    assert rt.device_layout(scenes("scene.txt"))[0].light_root == -1
