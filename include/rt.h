@@ -278,9 +278,9 @@ int rt_trace_rays(rt_context* ctx, const float* org_dir, size_t n, uint32_t flag
                   int32_t* prim_id, float* t, float* hit_pos, float* normal3, int32_t* counts);
 
 /* rt_trace_rays for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (its main() allocates freely,
- * src/main.cu:418-460): it is for code under HIP graph capture, tight serving loops and harnesses that forbid
- * hipMalloc.  The call makes no hipMalloc / hipFree and no host copy: rays in and results out are DEVICE pointers
- * (org_dir n x 6 floats; prim_id, t, hit_pos n x 3, normal3 n x 3 as in rt_trace_rays, each may be NULL), and the
+ * src/main.cu:418-460): it is for tight serving loops, harnesses that forbid hipMalloc and code meant to run under HIP
+ * graph capture (the call only launches: the kernels' attributes are set at rt_upload_scene; capture itself is untested).
+ * The call makes no hipMalloc / hipFree and no host copy: rays in and results out are DEVICE pointers (org_dir n x 6 floats; prim_id, t, hit_pos n x 3, normal3 n x 3 as in rt_trace_rays, each may be NULL), and the
  * ray queue, hit records and control words of the trace kernel live in a file-scope device array of the library
  * (12 MiB per GPU, held until the process ends).  n > RT_TRACE_NOALLOC_MAX_RAYS is refused with RT_ERR_LIMIT.
  * Work is enqueued on the context's stream (rt_set_stream); sync != 0 waits for it before returning.
