@@ -252,6 +252,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_FINISH_MIN
 #define RT_FINISH_MIN 12        // lanes back from a light query that get a (short) vertex pass of their own
 #endif
+#ifndef RT_WIDE7
+#define RT_WIDE7 1  // the shortcut walk's LDS window: wide nodes only, 112 bytes each (0 = padded items, 160 bytes a node: experiments)
+#endif
 #ifndef RT_WIDE_STEPS
 #define RT_WIDE_STEPS 2         // visits of wide (four-child) shortcut nodes per vote
 #endif
@@ -297,13 +300,24 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cache_base = (FAST && !TLDS) ? sc.short_base : 0;  // the LDS holds items [cache_base, cache_base + n_cached) (TLDS: all of them)
-    for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[4 * (size_t)cache_base + i];
-    int* stk = (int*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached)) + (size_t)wave * stack_entries * 64 + lane;
+    // W7: the window of the shortcut walk holds wide nodes only, seven float4s each (rt_device.h, WIDE7); n_cached = 2 x nodes.
+    // (Not in the variant with light queries: measured 2.4 % slower there at the same number of nodes, profiles/r03_ab.txt.)
+    constexpr bool W7 = RT_WIDE7 && FAST && !TLDS && !COOP;
+    const size_t cache_f4 = W7 ? (size_t)RT_WIDE7_F4 * (size_t)(n_cached >> 1) : RT_LDS_CACHE_FLOAT4S(n_cached);
+    if (W7) {
+        for (int i = threadIdx.x; i < RT_WIDE7_F4 * (n_cached >> 1); i += 64 * RT_MEGA_WAVES) {
+            const int w = i / RT_WIDE7_F4, p = i - w * RT_WIDE7_F4;
+            rt_lds[i] = sc.items[4 * (size_t)cache_base + 8 * (size_t)w + p];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 4 * n_cached; i += 64 * RT_MEGA_WAVES) rt_lds[RT_LDS_SLOT(i >> 2, i & 3, n_cached)] = sc.items[4 * (size_t)cache_base + i];
+    }
+    int* stk = (int*)(rt_lds + cache_f4) + (size_t)wave * stack_entries * 64 + lane;
     // the material table behind the stacks (n_mats_lds = 0: too many materials, they stay in device memory)
-    const int mats_lds = n_mats_lds > 0 ? (int)(RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16) : -1;
+    const int mats_lds = n_mats_lds > 0 ? (int)(cache_f4 + (size_t)RT_MEGA_WAVES * stack_entries * 16) : -1;
     for (int i = threadIdx.x; i < 3 * n_mats_lds; i += 64 * RT_MEGA_WAVES) rt_lds[mats_lds + i] = sc.mats[i];
     // COOP: behind the material table RT_LQ_CAP words per wave for the light loop's queue (wave_light_pdf_q)
-    [[maybe_unused]] volatile unsigned* lqueue = (volatile unsigned*)(rt_lds + RT_LDS_CACHE_FLOAT4S(n_cached) + (size_t)RT_MEGA_WAVES * stack_entries * 16 + 3 * (size_t)n_mats_lds) + wave * RT_LQ_CAP;
+    [[maybe_unused]] volatile unsigned* lqueue = (volatile unsigned*)(rt_lds + cache_f4 + (size_t)RT_MEGA_WAVES * stack_entries * 16 + 3 * (size_t)n_mats_lds) + wave * RT_LQ_CAP;
     __syncthreads();
     const bool use_bvh = (P.flags & RT_F_BVH) != 0;
     const bool spheres_on = (P.flags & RT_F_SPHERES) != 0 && sc.n_spheres > 0;
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (LTREE) {
                 // pdf_cos > 2e-12: pdf = pdf_cos / 2 + pdf_light / 2 is then above reflectType5's 1e-12 whatever the lights add, so the
                 // finishing pass never needs the incoming direction (material.h:324-327 keeps it when the pdf vanishes)
-                if (lq.pending && sc.light_root >= 0 && lq.pdf_cos > 2e-12f && light_query_begin(sc, t, lq.hitPos, lq.outgoing, lq.pdf_cos)) {
+                if (lq.pending && sc.light_root >= 0 && lq.pdf_cos > 2e-12f && light_query_begin(sc, t, lq.hitPos, lq.outgoing, lq.pdf_cos, W7 ? 64 : 80)) {
                     thr = ray.thr * lq.clr;  // (ray.thr * clr) * (pdf_cos / pdf): the first product now, the second when the sum is known
                     ri = ray.ri;
                     if (STATS) cn.lights += (uint32_t)sc.n_lights;  // what the reference's loop tests
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
             if (go) {  // main.cu:221-236
                 if (STATS) cn.rays++;
                 trav_begin(sc, t, ro, t.d, marching ? len2(marchVel) : 1e12f);
-                if (FAST) short_begin(sc, t);
+                if (FAST) short_begin(sc, t, W7 ? 64 : 80);
                 if (!use_bvh) trav_brute_force<STATS>(sc, t, cn);
             }
             RT_PROF_COUNT(cn, 5, RT_PROF_CLOCK() - pc0);
@@ -618,10 +632,10 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
                     RT_PROF_COUNT(cn, 0, 1);
                     RT_PROF_LANE(cn, 1);
                     RT_PROF_LANE(cn, 15);
-                    trav_step_wide<STATS, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                    trav_step_wide<STATS, TLDS, W7>(sc, t, stk, cn, n_cached, cache_base);
 #pragma unroll
                     for (int k = 1; k < (TLDS ? RT_WIDE_STEPS_TINY : RT_WIDE_STEPS); k++)
-                        if (trav_at_wide(sc, t)) trav_step_wide<STATS, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                        if (trav_at_wide(sc, t)) trav_step_wide<STATS, TLDS, W7>(sc, t, stk, cn, n_cached, cache_base);
                 }
             }
 #if RT_CYCLE_PROF == 2
@@ -635,12 +649,12 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Sce
 #if RT_INNER_ROLLED  // (experiments: ONE copy of the visit's code in a counted loop)
 #pragma unroll 1
                 for (int k = 0; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)
-                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, W7 ? 0 : n_cached, cache_base);
 #else
-                trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, W7 ? 0 : n_cached, cache_base);
 #pragma unroll
                 for (int k = 1; k < (FAST ? (TLDS ? RT_INNER_STEPS_TINY : RT_INNER_STEPS_SHORT) : RT_INNER_STEPS); k++)  // (more visits before the next vote: a vote costs a tenth of a step)
-                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, n_cached, cache_base);
+                    if (trav_at_inner(sc, t) && !(FAST && trav_at_wide(sc, t))) trav_step_inner<STATS, BIG, TLDS>(sc, t, stk, cn, W7 ? 0 : n_cached, cache_base);
 #endif
             }
         }
@@ -3262,7 +3276,9 @@ struct TraceCfg {
 };
 
 #define RT_LDS_MATS_MAX 128  // material tables up to this size go to LDS in the path kernel (48 B each)
-TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = false, bool fast = false) {
+// compact_wide (the path kernel's shortcut walk): the window holds wide nodes only, 112 bytes each (rt_device.h, WIDE7), unless the whole
+// item stream fits (then the kernel variant that keeps everything in the LDS runs, with the padded records).
+TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = false, bool fast = false, bool compact_wide = false) {
     TraceCfg t;
     // (shortcut walk: a search that is not certified walks the reference's tree with the same stack)
     t.stack_entries = std::max(fast ? std::max(c->bvh_depth, c->short_depth) : c->bvh_depth, 1);
@@ -3271,13 +3287,22 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48 + queue_bytes;
     const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
-    if (const char* e = getenv("RT_LDS_NODES")) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(e)));  // experiments only
+    const char* cap = getenv("RT_LDS_NODES");  // experiments only
+    if (cap) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(cap)));
     t.n_cached = (int)std::min<size_t>(cache_nodes, (size_t)(c->sc.n_inner - (fast ? c->sc.short_base : 0)));
     // a scene whose whole item stream fits (the Cornell box): the triangles too, so that a leaf step reads the LDS
     // instead of L1 (path-parallel kernel only: its leaf step knows)
     const size_t all_items = (size_t)c->sc.n_inner + (size_t)c->sc.n_tris + (c->sc.n_light_items ? 1 + (size_t)c->sc.n_light_items : 0);  // (the light items stand behind the triangles)
-    if (with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS")) t.n_cached = (int)all_items;
+    const bool everything = with_mats && c->sc.n_tris > 0 && c->sc.n_sub == 0 && all_items <= cache_nodes && !getenv("RT_NO_LDS_TRIS");
+    if (everything) t.n_cached = (int)all_items;
     t.lds_bytes = RT_LDS_CACHE_FLOAT4S(t.n_cached) * 16 + stack_bytes;
+    if (RT_WIDE7 && fast && compact_wide && !everything) {
+        size_t wide_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_WIDE7_F4 * 16) : 0;
+        if (cap) wide_nodes = std::min<size_t>(wide_nodes, (size_t)std::max(0, atoi(cap)) / 2);
+        wide_nodes = std::min<size_t>(wide_nodes, (size_t)c->sc.wide_n / 2);
+        t.n_cached = (int)(2 * wide_nodes);
+        t.lds_bytes = wide_nodes * RT_WIDE7_F4 * 16 + stack_bytes;
+    }
     t.grid = c->num_cus;
     return t;
 }
@@ -3423,7 +3448,7 @@ int render_paths(rt_context* c, const Params& P, float* accum, bool want_stats, 
                       // (many lights but no light tree -- the two-child shortcut form of the experiments: the shortcut kernel would run the
                       // plain loop over all lights per lane; the reference-walk kernel has the wave-cooperative loop)
                       !(c->sc.n_lights >= RT_LIGHTS_COOP_MIN && c->sc.light_root < 0);
-    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true, fast);
+    const TraceCfg tc = trace_cfg(c, RT_MEGA_WAVES, true, fast, c->sc.n_lights < RT_LIGHTS_COOP_MIN);
     int rc = set_mega_lds(c, tc);
     if (rc != RT_OK) return rc;
     const size_t slots = (size_t)P.n_tiles * 64;  // pixels incl. the padding of edge tiles

@@ -667,7 +667,7 @@ __device__ __forceinline__ void visit_triangle(const Scene& sc, Trav& t, const i
 }
 
 __device__ __forceinline__ bool trav_at_wide(const Scene& sc, const Trav& t);
-template <bool STATS, bool ALL_CACHED = false>
+template <bool STATS, bool ALL_CACHED = false, bool WIDE7 = false>
 __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached, int cache_base);
 
 // ONE traversal step of this lane (t.cur != RT_TRAV_DONE on entry): an inner-node visit or one
@@ -744,7 +744,13 @@ __device__ __forceinline__ float wide_child(f3 inv, f3 noi, float limT, float nx
 
 // One visit of a wide shortcut node (trav_at_wide(t)).  cache_base / n_cached as in trav_step_inner; both items of the
 // node must be inside the window for the LDS path.
-template <bool STATS, bool ALL_CACHED>
+// WIDE7 (the path kernel of a scene that does not sit in the LDS entirely): the LDS window holds WIDE nodes only, as records of the seven
+// float4s a visit reads (112 bytes a node instead of the 160 of two padded items: 43 % more nodes in the window); n_cached still counts
+// items (two per node) and Trav::sgx.. are 64 (short_begin / light_query_begin with sg = 64), as in device memory.
+#ifndef RT_WIDE7_F4
+#define RT_WIDE7_F4 7
+#endif
+template <bool STATS, bool ALL_CACHED, bool WIDE7>
 __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* stk, Counters& cn, int n_cached, int cache_base) {
     // a0..a2: the NEAR planes of the four children (x, y, z), b0..b2 the FAR ones, a3 the entries.  Which of a node's min / max
     // pieces that is follows from the sign of the ray's direction (Trav::sgx..): the addresses differ, not the arithmetic.
@@ -756,12 +762,21 @@ __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* st
         typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f;
         static_assert(RT_LDS_REC == 5, "Trav::sgx.. assume records of five float4s per item in the LDS window");
         typedef const volatile __attribute__((address_space(3))) char* lds_bytes;
-        const lds_bytes c = (lds_bytes)rt_lds + 16 * RT_LDS_SLOT(rel, 0, n_cached);
-        const v4f p0 = *(lds_v4f)(c + t.sgx), p1 = *(lds_v4f)(c + t.sgy + 16), p2 = *(lds_v4f)(c + t.sgz + 32), p3 = *(lds_v4f)(c + 48),
-                  p4 = *(lds_v4f)(c - t.sgx + 80), p5 = *(lds_v4f)(c - t.sgy + 96), p6 = *(lds_v4f)(c - t.sgz + 112);
-        a0 = make_float4(p0.x, p0.y, p0.z, p0.w); a1 = make_float4(p1.x, p1.y, p1.z, p1.w); a2 = make_float4(p2.x, p2.y, p2.z, p2.w);
-        a3 = make_float4(p3.x, p3.y, p3.z, p3.w); b0 = make_float4(p4.x, p4.y, p4.z, p4.w); b1 = make_float4(p5.x, p5.y, p5.z, p5.w);
-        b2 = make_float4(p6.x, p6.y, p6.z, p6.w);
+        if (WIDE7) {
+            const lds_bytes c = (lds_bytes)rt_lds + (int)__umul24((unsigned)rel, 8 * RT_WIDE7_F4);  // (rel / 2) nodes of 16 * 7 bytes
+            const v4f p0 = *(lds_v4f)(c + t.sgx), p1 = *(lds_v4f)(c + t.sgy + 16), p2 = *(lds_v4f)(c + t.sgz + 32), p3 = *(lds_v4f)(c + 48),
+                      p4 = *(lds_v4f)(c - t.sgx + 64), p5 = *(lds_v4f)(c - t.sgy + 80), p6 = *(lds_v4f)(c - t.sgz + 96);
+            a0 = make_float4(p0.x, p0.y, p0.z, p0.w); a1 = make_float4(p1.x, p1.y, p1.z, p1.w); a2 = make_float4(p2.x, p2.y, p2.z, p2.w);
+            a3 = make_float4(p3.x, p3.y, p3.z, p3.w); b0 = make_float4(p4.x, p4.y, p4.z, p4.w); b1 = make_float4(p5.x, p5.y, p5.z, p5.w);
+            b2 = make_float4(p6.x, p6.y, p6.z, p6.w);
+        } else {
+            const lds_bytes c = (lds_bytes)rt_lds + 16 * RT_LDS_SLOT(rel, 0, n_cached);
+            const v4f p0 = *(lds_v4f)(c + t.sgx), p1 = *(lds_v4f)(c + t.sgy + 16), p2 = *(lds_v4f)(c + t.sgz + 32), p3 = *(lds_v4f)(c + 48),
+                      p4 = *(lds_v4f)(c - t.sgx + 80), p5 = *(lds_v4f)(c - t.sgy + 96), p6 = *(lds_v4f)(c - t.sgz + 112);
+            a0 = make_float4(p0.x, p0.y, p0.z, p0.w); a1 = make_float4(p1.x, p1.y, p1.z, p1.w); a2 = make_float4(p2.x, p2.y, p2.z, p2.w);
+            a3 = make_float4(p3.x, p3.y, p3.z, p3.w); b0 = make_float4(p4.x, p4.y, p4.z, p4.w); b1 = make_float4(p5.x, p5.y, p5.z, p5.w);
+            b2 = make_float4(p6.x, p6.y, p6.z, p6.w);
+        }
     } else {
         // (32-bit byte offsets from the first wide node: the range of wide nodes is far below 4 GB; uniform base + lane offset)
         const char* wb = (const char*)(sc.items + 4 * (size_t)sc.wide_lo);
@@ -837,13 +852,13 @@ __device__ __forceinline__ void trav_step_leaf(const Scene& sc, Trav& t, const i
 // search down the shortcut tree if this ray may use it.  short_certified: the search is over (t.cur == RT_TRAV_DONE);
 // true = the result stands (also: no hit at all -- the shortcut walk tests every triangle whose padded boxes the ray
 // reaches, so the reference finds none either --, or the search already was the reference's walk).
-__device__ __forceinline__ void short_begin(const Scene& sc, Trav& t) {
+__device__ __forceinline__ void short_begin(const Scene& sc, Trav& t, int sg = 80) {  // sg: see Trav::sgx (64 in a kernel with the WIDE7 window)
     t.bestLeaf = -1;
     // (wide nodes form bound / d - o / d: o / d must be finite, or a box the ray reaches could test as missed)
     const bool finite_od = sc.wide_n == 0 || (fabsf(t.oxy.x * t.ixy.x) < INFINITY && fabsf(t.oxy.y * t.ixy.y) < INFINITY && fabsf(t.oz * t.iz) < INFINITY);
-    t.sgx = t.ixy.x < 0.0f ? 80 : 0;
-    t.sgy = t.ixy.y < 0.0f ? 80 : 0;
-    t.sgz = t.iz < 0.0f ? 80 : 0;
+    t.sgx = t.ixy.x < 0.0f ? sg : 0;
+    t.sgy = t.ixy.y < 0.0f ? sg : 0;
+    t.sgz = t.iz < 0.0f ? sg : 0;
     if (t.cur != RT_TRAV_DONE && !t.axis_parallel && t.slack < INFINITY && finite_od) {
         t.cur = sc.short_root;
         t.rival = 1e12f;
@@ -868,7 +883,7 @@ __device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t) 
 // distance, a leaf is one light item, a hit adds its term (visit_triangle).  The query's state rides in fields a closest-hit
 // search does not need meanwhile: minD2 = the sum so far, hitTri = nonzero terms so far, hitT = pdf_cos, bestLeaf = the mode.
 // False: this ray cannot use the tree (same conditions as short_begin) -- the caller runs the loop over all lights instead.
-__device__ __forceinline__ bool light_query_begin(const Scene& sc, Trav& t, f3 o, f3 d, float pdf_cos) {
+__device__ __forceinline__ bool light_query_begin(const Scene& sc, Trav& t, f3 o, f3 d, float pdf_cos, int sg = 80) {
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const bool ok = fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY && fabsf(o.x * inv.x) < INFINITY &&
                     fabsf(o.y * inv.y) < INFINITY && fabsf(o.z * inv.z) < INFINITY &&
@@ -880,9 +895,9 @@ __device__ __forceinline__ bool light_query_begin(const Scene& sc, Trav& t, f3 o
     t.ixy = (v2f){inv.x, inv.y};
     t.iz = inv.z;
     t.axis_parallel = false;
-    t.sgx = inv.x < 0.0f ? 80 : 0;
-    t.sgy = inv.y < 0.0f ? 80 : 0;
-    t.sgz = inv.z < 0.0f ? 80 : 0;
+    t.sgx = inv.x < 0.0f ? sg : 0;
+    t.sgy = inv.y < 0.0f ? sg : 0;
+    t.sgz = inv.z < 0.0f ? sg : 0;
     t.sp = 0;
     t.limT = 3e38f;   // all hits: no child is too far
     t.rival = -1.0f;  // (not a shortcut search: nothing to certify)
