@@ -291,8 +291,16 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 // BIG: the scene has leaf sub-trees (rt_device.h).  EXTRA: RT_F_VOLUME and / or RT_F_RAYMARCH
 // (both off in the reference's config.h): seven more registers of path state (volume density + colour, march velocity).
 // FAST: closest-hit searches go down the shortcut tree first (rt_device.h; the scene has one, no STATS of the reference's walk).
+#ifndef RT_PATHS_MIN_WAVES
+#define RT_PATHS_BOUNDS __launch_bounds__(64 * RT_MEGA_WAVES)
+#else  // (experiments: blocks of fewer waves, several per CU, and a register budget for RT_PATHS_MIN_WAVES waves per SIMD)
+#define RT_PATHS_BOUNDS __launch_bounds__(64 * RT_MEGA_WAVES, RT_PATHS_MIN_WAVES)
+#endif
+#ifndef RT_LDS_BUDGET_BYTES
+#define RT_LDS_BUDGET_BYTES (160 * 1024 - 1024)  // of one block: leave a little for the runtime
+#endif
 template <bool STATS, bool BIG, bool EXTRA, bool COOP, bool TLDS = false, bool FAST = false>
-__global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
+__global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float* __restrict__ samples,
                                                                               unsigned int* __restrict__ path_counter,
                                                                               unsigned long long* __restrict__ stats, int n_cached,
                                                                               int stack_entries, int chunk_k0, int chunk_S,
@@ -3285,7 +3293,7 @@ TraceCfg trace_cfg(rt_context* c, int waves = RT_TRACE_WAVES, bool with_mats = f
     t.n_mats_lds = (with_mats && c->sc.n_mats <= RT_LDS_MATS_MAX && !getenv("RT_NO_LDS_MATS")) ? c->sc.n_mats : 0;
     const size_t queue_bytes = (with_mats && c->sc.n_lights >= RT_LIGHTS_COOP_MIN) ? (size_t)waves * RT_LQ_CAP * 4 : 0;  // the light loop's queue
     const size_t stack_bytes = (size_t)waves * t.stack_entries * 64 * sizeof(int) + (size_t)t.n_mats_lds * 48 + queue_bytes;
-    const size_t budget = 160 * 1024 - 1024;  // leave a little for the runtime
+    const size_t budget = RT_LDS_BUDGET_BYTES;
     size_t cache_nodes = budget > stack_bytes ? (budget - stack_bytes) / (RT_LDS_CACHE_FLOAT4S(1) * 16) : 0;
     const char* cap = getenv("RT_LDS_NODES");  // experiments only
     if (cap) cache_nodes = std::min<size_t>(cache_nodes, (size_t)std::max(0, atoi(cap)));
@@ -3408,7 +3416,7 @@ int set_mega_lds(rt_context* c, const TraceCfg& t) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t.lds_bytes));
     for (int v = 0; v < 8; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)paths_kernel_variant((v & 1) != 0, true, false, (v & 2) != 0, (v & 4) != 0, true),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BUDGET_BYTES));
     for (int v = 0; v < 8; v++)
         HIP_TRY(c, hipFuncSetAttribute((const void*)pool_kernel_variant((v & 1) != 0, (v & 2) != 0, (v & 4) != 0),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
