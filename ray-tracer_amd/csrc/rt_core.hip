@@ -274,6 +274,9 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #define RT_NT_STORE 1  // a path's radiance is written once and read once, by another kernel: stored past the caches (-1 % frame time,
                        // more bytes at the HBM: 3.18 vs 2.93 GB per frame of scene.txt; profiles/r02_ab.txt)
 #endif
+#ifndef RT_HIT_PREFETCH
+#define RT_HIT_PREFETCH 1  // a vertex pass fetches its hit triangles' item, leaf box and cold data in one go at its top (rt_device.h, HitFetch)
+#endif
 #ifndef RT_LEAF_STEPS
 #define RT_LEAF_STEPS 1   // triangle tests per vote
 #endif
@@ -378,7 +381,13 @@ __global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float
             [[maybe_unused]] const unsigned long long pc0 = RT_PROF_CLOCK();
             RT_PROF_COUNT(cn, 3, 1);
             if ((unsigned)(t.cur + 2) < 2u) RT_PROF_LANE(cn, 4);
-            if (FAST && !finish_only && t.cur == RT_TRAV_DONE && !finishing && !short_certified(sc, t)) {
+            // PF: what the pass reads about the hit triangles of its lanes, fetched together up front (rt_device.h, HitFetch)
+            constexpr bool PF = RT_HIT_PREFETCH && FAST && (!COOP || RT_HIT_PREFETCH == 2);
+            HitFetch pf;
+            const bool pf_on = PF && !finish_only && t.cur == RT_TRAV_DONE && !finishing && t.hitTri >= 0 && t.bestLeaf != -2;
+            if (pf_on) hit_fetch(sc, t.hitTri, pf);
+            // (short_certified reads the box only for a lane with a hit whose search did not give up: pf_on)
+            if (FAST && !finish_only && t.cur == RT_TRAV_DONE && !finishing && !short_certified<PF>(sc, t, pf.mn, pf.mx)) {
                 // the shortcut walk's result does not prove what the reference's walk returns: this lane walks the
                 // reference's tree now (main.cu:221-283) and comes back to a later vertex pass
                 if (STATS) cn.rewalks++;
@@ -425,7 +434,7 @@ __global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float
                             // scattered inside the volume: `continue`, main.cu:350-352
                         } else {
                             if (STATS) cn.hits++;
-                            if (shade_triangle<STATS>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn, COOP ? &lq : nullptr, mats_lds)) {  // main.cu:357-360
+                            if (shade_triangle<STATS, PF>(sc, ray, t.hit_pos(), t.hitTri, rng, bb, cn, COOP ? &lq : nullptr, mats_lds, pf)) {  // main.cu:357-360
                                 e = ray.emission * ray.thr;
                                 alive = false;
                             } else if (!COOP || !lq.pending) {

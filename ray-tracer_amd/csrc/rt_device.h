@@ -866,12 +866,19 @@ __device__ __forceinline__ void short_begin(const Scene& sc, Trav& t, int sg = 8
         t.rival = -1.0f;
     }
 }
-__device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t) {
+template <bool HAVE_BOX = false>  // HAVE_BOX: (bmn, bmx) is the box of the hit's leaf, fetched already (hit_fetch) wherever this gets as far as reading it
+__device__ __forceinline__ bool short_certified(const Scene& sc, const Trav& t, float4 bmn = make_float4(0.f, 0.f, 0.f, 0.f),
+                                                float4 bmx = make_float4(0.f, 0.f, 0.f, 0.f)) {
     if (t.rival < 0.0f) return true;
     if (t.bestLeaf == -2) return false;  // the search gave up (stack room, trav_step_wide)
     if (t.hitTri < 0) return true;
-    const int leaf = __float_as_int(sc.items[4 * ((size_t)sc.n_inner + t.hitTri) + 3].x);
-    const float4 mn = sc.ref_boxes[2 * (size_t)leaf], mx = sc.ref_boxes[2 * (size_t)leaf + 1];
+    float4 mn, mx;
+    if (HAVE_BOX) {
+        mn = bmn; mx = bmx;
+    } else {
+        const int leaf = __float_as_int(sc.items[4 * ((size_t)sc.n_inner + t.hitTri) + 3].x);
+        mn = sc.ref_boxes[2 * (size_t)leaf]; mx = sc.ref_boxes[2 * (size_t)leaf + 1];
+    }
     const float bd = aabb_distance(t.o(), t.inv(), mk(mn.x, mn.y, mn.z), mk(mx.x, mx.y, mx.z));
     const float bd2 = bd * bd;
     return bd2 < t.rival && t.minD2 < t.rival && bd2 <= t.minD2 * 1.00001f + 0.5f * t.slack;
@@ -1061,11 +1068,33 @@ __device__ __forceinline__ int tri_id(const Scene& sc, int place) {
     return __float_as_int(sc.items[4 * ((size_t)sc.n_inner + place) + 2].w);
 }
 
-__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int place, f3 hitPos) {  // material.h:44-62
+// What a vertex pass reads about a hit triangle at its top (hit_fetch): the triangle's item -- all four pieces, once, for the certificate
+// (the id of its reference leaf) AND the shading (vertex, edges, id) -- and the leaf's box behind it: a chain of four dependent
+// requests (item -> leaf box | cold data -> texel) instead of five (leaf id -> leaf box -> item -> cold data -> texel).  (The cold
+// data fetched up front as well was measured: 36 more live registers, spills.)
+struct HitFetch {
+    float4 h0, h1, h2, mn, mx;
+};
+__device__ __forceinline__ void hit_fetch(const Scene& sc, int place, HitFetch& f) {
     const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
-    const float4 h0 = t[0], h1 = t[1], h2 = t[2];
+    f.h0 = t[0]; f.h1 = t[1]; f.h2 = t[2];
+    float4 h3 = t[3];
+    asm volatile("" : "+v"(h3.x), "+v"(f.h0.x), "+v"(f.h1.x), "+v"(f.h2.x));  // (the four pieces of the item in one go)
+    const int leaf = __float_as_int(h3.x);
+    f.mn = sc.ref_boxes[2 * (size_t)leaf]; f.mx = sc.ref_boxes[2 * (size_t)leaf + 1];
+}
+
+template <bool PF = false>  // PF: pf holds the records (hit_fetch)
+__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int place, f3 hitPos, const HitFetch& pf) {  // material.h:44-62
+    const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
+    float4 h0, h1, h2, c0, c1, c2, c3;
+    if (PF) {
+        h0 = pf.h0; h1 = pf.h1; h2 = pf.h2;
+    } else {
+        h0 = t[0]; h1 = t[1]; h2 = t[2];
+    }
     const float4* c = sc.tri_cold + 4 * (size_t)__float_as_int(h2.w);  // (cold data stays in the reference's order)
-    const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
     const f3 bary = barycentric(mk(h0.x, h0.y, h0.z), mk(h0.w, h1.x, h1.y), mk(h1.z, h1.w, h2.x), hitPos);
     const f3 n0 = mk(c0.x, c0.y, c0.z), n1 = mk(c0.w, c1.x, c1.y), n2 = mk(c1.z, c1.w, c2.x);
     HitFrame f;
@@ -1075,6 +1104,11 @@ __device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int place, f3 hit
     f.v = bary.x * c2.z + bary.y * c3.x + bary.z * c3.z;
     f.mat = __float_as_int(c3.w);
     return f;
+}
+
+__device__ __forceinline__ HitFrame hit_frame(const Scene& sc, int place, f3 hitPos) {
+    HitFetch none;
+    return hit_frame<false>(sc, place, hitPos, none);
 }
 
 // reflectType5 (material.h:280-336) sums the pdf of EVERY importance-sampled triangle for the sampled direction
@@ -1091,12 +1125,12 @@ struct LightQuery {
 };
 
 // Material::reflect, material.h:41-106.  Returns true when the path terminates.
-template <bool STATS>
+template <bool STATS, bool PF = false>
 // The bounce's dimensions 8+8j .. 15+8j are Philox blocks bb and bb+1 (bb = 2 + 2j): A = dims k0..k3,
 // B = dims k4..k7, consumed in the reference's call order.
 __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, const Rng& rng,
-                                               uint32_t bb, Counters& cn, LightQuery* lq = nullptr, int mats_lds = -1) {
-    const HitFrame hf = hit_frame(sc, tri, hitPos);
+                                               uint32_t bb, Counters& cn, LightQuery* lq, int mats_lds, const HitFetch& pf) {
+    const HitFrame hf = hit_frame<PF>(sc, tri, hitPos, pf);
     const f3 normal = hf.normal;
     int type = 127;  // out-of-range material id -> "the color of error"
     f3 clr = mk(0.f, 0.f, 0.f);
@@ -1276,6 +1310,13 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.emission = mk(1.0f, 0.0f, 1.0f);
             return true;
     }
+}
+
+template <bool STATS>
+__device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, f3 hitPos, int tri, const Rng& rng, uint32_t bb, Counters& cn,
+                                               LightQuery* lq = nullptr, int mats_lds = -1) {
+    HitFetch none;
+    return shade_triangle<STATS, false>(sc, ray, hitPos, tri, rng, bb, cn, lq, mats_lds, none);
 }
 
 // The loop of material.h:315-323 as the reference runs it: every light, in list order.
