@@ -220,6 +220,12 @@ __global__ __launch_bounds__(64 * RT_MEGA_WAVES) void rt_render_kernel(Scene sc,
 #ifndef RT_TRI_MIN
 #define RT_TRI_MIN 12  // run a triangle-test iteration when this many lanes wait at a leaf (0 = mixed steps)
 #endif
+#ifndef RT_REGEN_MIN_RUNS
+#define RT_REGEN_MIN_RUNS 44  // the two votes on a shortcut tree over runs (the bundled scenes; sweep in profiles/r03_ab.txt)
+#endif
+#ifndef RT_TRI_MIN_RUNS
+#define RT_TRI_MIN_RUNS 16
+#endif
 #ifndef RT_BIG_LEAF
 #define RT_BIG_LEAF 2           // leaves with at least this many triangles may get a sub-tree (rt_device.h) ...
 #endif
@@ -374,7 +380,8 @@ __global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float
         // so RT_FINISH_MIN lanes waiting for it get a pass of their own, which serves them alone (finish_only).
         constexpr bool LTREE = FAST && COOP;
         const bool finishing = LTREE && t.cur == RT_TRAV_DONE && t.bestLeaf <= RT_LQ_RUNNING;
-        const bool full_pass = __popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : COOP ? RT_REGEN_MIN_COOP : RT_REGEN_MIN) || mTrav == 0;
+        // (a shortcut tree over runs -- the bundled scenes -- takes other votes than one over a frontier of sub-trees: RT_*_RUNS)
+        const bool full_pass = __popcll(mNeed) >= ((FAST && TLDS) ? RT_REGEN_MIN_TINY : COOP ? RT_REGEN_MIN_COOP : (FAST && sc.short_runs) ? RT_REGEN_MIN_RUNS : RT_REGEN_MIN) || mTrav == 0;
         const bool finish_only = LTREE && !full_pass && __popcll(__ballot(finishing)) >= RT_FINISH_MIN;
         if (full_pass || finish_only) {
             if (mNeed == 0) break;  // every lane idle: no paths left
@@ -622,7 +629,7 @@ __global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float
             RT_PROF_COUNT(cn, base + 3, nV);
         }
 #endif
-        if (__popcll(mLeaf) >= RT_TRI_MIN || __ballot(at_inner) == 0) {
+        if (__popcll(mLeaf) >= ((FAST && !TLDS && !COOP && sc.short_runs) ? RT_TRI_MIN_RUNS : RT_TRI_MIN) || __ballot(at_inner) == 0) {
             RT_PROF_COUNT(cn, 13, 1);
             if (at_leaf) {
                 RT_PROF_COUNT(cn, 0, 1);
