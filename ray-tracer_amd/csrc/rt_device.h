@@ -1068,18 +1068,26 @@ __device__ __forceinline__ int tri_id(const Scene& sc, int place) {
     return __float_as_int(sc.items[4 * ((size_t)sc.n_inner + place) + 2].w);
 }
 
+#ifndef RT_HIT_PREFETCH_RNG
+#define RT_HIT_PREFETCH_RNG 1
+#endif
 // What a vertex pass reads about a hit triangle at its top (hit_fetch): the triangle's item -- all four pieces, once, for the certificate
 // (the id of its reference leaf) AND the shading (vertex, edges, id) -- and the leaf's box behind it: a chain of four dependent
 // requests (item -> leaf box | cold data -> texel) instead of five (leaf id -> leaf box -> item -> cold data -> texel).  (The cold
 // data fetched up front as well was measured: 36 more live registers, spills.)
 struct HitFetch {
     float4 h0, h1, h2, mn, mx;
+    uint4 A;  // the bounce's first Philox block (every material that draws numbers starts with it), formed while the item is on its way
 };
-__device__ __forceinline__ void hit_fetch(const Scene& sc, int place, HitFetch& f) {
+__device__ __forceinline__ void hit_fetch(const Scene& sc, int place, HitFetch& f, const Rng& rng, uint32_t bb) {
     const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
     f.h0 = t[0]; f.h1 = t[1]; f.h2 = t[2];
     float4 h3 = t[3];
     asm volatile("" : "+v"(h3.x), "+v"(f.h0.x), "+v"(f.h1.x), "+v"(f.h2.x));  // (the four pieces of the item in one go)
+#if RT_HIT_PREFETCH_RNG
+    f.A = rng.block(bb);
+    asm volatile("" : "+v"(f.A.x), "+v"(f.A.y), "+v"(f.A.z), "+v"(f.A.w), "+v"(h3.x));  // (... before the item is looked at)
+#endif
     const int leaf = __float_as_int(h3.x);
     f.mn = sc.ref_boxes[2 * (size_t)leaf]; f.mx = sc.ref_boxes[2 * (size_t)leaf + 1];
 }
@@ -1184,7 +1192,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
     switch (type) {
         case 0: {  // reflectType0, material.h:182-202
             ray.o = hitPos;
-            const uint4 A = rng.block(bb);
+            const uint4 A = (PF && RT_HIT_PREFETCH_RNG) ? pf.A : rng.block(bb);
             if (u01(A.x) < p1) {
                 ray.thr = ray.thr * mk(0.95f, 0.95f, 0.95f);
                 ray.d = reflect(ray.d, normal);
@@ -1221,7 +1229,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
                 const double x = (double)(1 - cos_theta);
                 const double x2 = x * x;
                 r0 = (float)((double)r0 + (double)(1 - r0) * (x2 * x2 * x));
-                if (r0 > u01(rng.block(bb).x)) will_refract = false;
+                if (r0 > u01(((PF && RT_HIT_PREFETCH_RNG) ? pf.A : rng.block(bb)).x)) will_refract = false;
             }
             if (will_refract) {
                 ray.d = refract(ray.d, normal2, ri);
@@ -1236,7 +1244,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             const f3 normal2 = (dot(normal, ray.d) < 0.0f) ? normal : (normal * -1.0f);
             ray.thr = ray.thr * clr0;
             ray.o = hitPos;
-            const uint4 A = rng.block(bb);
+            const uint4 A = (PF && RT_HIT_PREFETCH_RNG) ? pf.A : rng.block(bb);
             ray.d = normalize(normal2 + rand_sphere_vec(u01(A.x), u01(A.y)));
             ray.o = ray.o + ray.d * 1e-5f;
             return false;
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.thr = ray.thr * clr;
             ray.o = hitPos;
             ray.d = reflect(ray.d, normal);
-            const uint4 A = rng.block(bb);
+            const uint4 A = (PF && RT_HIT_PREFETCH_RNG) ? pf.A : rng.block(bb);
             ray.d = ray.d + rand_sphere_vec(u01(A.x), u01(A.y)) * p1;
             ray.o = ray.o + ray.d * 1e-5f;
             return false;
@@ -1255,7 +1263,7 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             ray.o = hitPos;
             f3 outgoing;
             bool sampledLight = false;
-            const uint4 A = rng.block(bb);
+            const uint4 A = (PF && RT_HIT_PREFETCH_RNG) ? pf.A : rng.block(bb);
             if (sc.n_lights > 0) {
                 if (u01(A.x) < 0.5f) {  // dims k0 (choice), k1 (raw pick), k2, k3
                     const uint32_t pick = A.y % (uint32_t)sc.n_lights;
