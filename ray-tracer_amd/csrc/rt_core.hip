@@ -392,7 +392,7 @@ __global__ RT_PATHS_BOUNDS void rt_render_paths_kernel(Scene sc, Params P, float
             constexpr bool PF = RT_HIT_PREFETCH && FAST && (!COOP || RT_HIT_PREFETCH == 2);
             HitFetch pf;
             const bool pf_on = PF && !finish_only && t.cur == RT_TRAV_DONE && !finishing && t.hitTri >= 0 && t.bestLeaf != -2;
-            if (pf_on) hit_fetch(sc, t.hitTri, pf, rng, (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2);
+            if (pf_on) hit_fetch<TLDS>(sc, t.hitTri, pf, rng, (RT_RNG_DIM_BOUNCE0 + RT_RNG_DIMS_PER_BOUNCE * (uint32_t)bounce) >> 2, n_cached);
             // (short_certified reads the box only for a lane with a hit whose search did not give up: pf_on)
             if (FAST && !finish_only && t.cur == RT_TRAV_DONE && !finishing && !short_certified<PF>(sc, t, pf.mn, pf.mx)) {
                 // the shortcut walk's result does not prove what the reference's walk returns: this lane walks the

@@ -1068,6 +1068,9 @@ __device__ __forceinline__ int tri_id(const Scene& sc, int place) {
     return __float_as_int(sc.items[4 * ((size_t)sc.n_inner + place) + 2].w);
 }
 
+#ifndef RT_HIT_FETCH_LDS
+#define RT_HIT_FETCH_LDS 1
+#endif
 #ifndef RT_HIT_PREFETCH_RNG
 #define RT_HIT_PREFETCH_RNG 1
 #endif
@@ -1079,11 +1082,17 @@ struct HitFetch {
     float4 h0, h1, h2, mn, mx;
     uint4 A;  // the bounce's first Philox block (every material that draws numbers starts with it), formed while the item is on its way
 };
-__device__ __forceinline__ void hit_fetch(const Scene& sc, int place, HitFetch& f, const Rng& rng, uint32_t bb) {
-    const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
-    f.h0 = t[0]; f.h1 = t[1]; f.h2 = t[2];
-    float4 h3 = t[3];
-    asm volatile("" : "+v"(h3.x), "+v"(f.h0.x), "+v"(f.h1.x), "+v"(f.h2.x));  // (the four pieces of the item in one go)
+template <bool TLDS = false>  // TLDS: the whole item stream sits in the LDS (n_cached items): the triangle's record is read there
+__device__ __forceinline__ void hit_fetch(const Scene& sc, int place, HitFetch& f, const Rng& rng, uint32_t bb, int n_cached = 0) {
+    float4 h3;
+    if (TLDS && RT_HIT_FETCH_LDS) {
+        load_cached_item(sc.n_inner + place, n_cached, f.h0, f.h1, f.h2, h3);
+    } else {
+        const float4* t = sc.items + 4 * ((size_t)sc.n_inner + place);
+        f.h0 = t[0]; f.h1 = t[1]; f.h2 = t[2];
+        h3 = t[3];
+        asm volatile("" : "+v"(h3.x), "+v"(f.h0.x), "+v"(f.h1.x), "+v"(f.h2.x));  // (the four pieces of the item in one go)
+    }
 #if RT_HIT_PREFETCH_RNG
     f.A = rng.block(bb);
     asm volatile("" : "+v"(f.A.x), "+v"(f.A.y), "+v"(f.A.z), "+v"(f.A.w), "+v"(h3.x));  // (... before the item is looked at)
