@@ -1141,16 +1141,6 @@ struct LightQuery {
     float pdf_cos;
 };
 
-// A record every lane of the wave reads at the SAME address (a loop over the lights, the same light for all): through the constant
-// address space, so that the compiler makes it ONE scalar load per wave instead of a 64-lane vector request to one address.  The
-// memory is written by nobody while a kernel runs.  (An address that is not uniform after all just becomes a vector load.)
-__device__ __forceinline__ float4 load_uniform_f4(const float4* p) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f v = *(const __attribute__((address_space(4))) v4f*)(uintptr_t)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ int load_uniform_i(const int* p) { return *(const __attribute__((address_space(4))) int*)(uintptr_t)p; }
-
 // Material::reflect, material.h:41-106.  Returns true when the path terminates.
 template <bool STATS, bool PF = false>
 // The bounce's dimensions 8+8j .. 15+8j are Philox blocks bb and bb+1 (bb = 2 + 2j): A = dims k0..k3,
@@ -1305,9 +1295,9 @@ __device__ __forceinline__ bool shade_triangle(const Scene& sc, PathState& ray, 
             }
             float pdf_light = 0.0f;
             for (int i = 0; i < sc.n_lights; i++) {  // O(numLights), material.h:315-323, in the reference's order
-                const int pj = load_uniform_i(sc.light_place + i);
-                const float4 l0 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 0)), l1 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 1)),
-                             l2 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 2)), l3 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 3));
+                const int pj = sc.light_place[i];
+                const float4 l0 = sc.lights[RT_LIGHT_F4(pj, 0)], l1 = sc.lights[RT_LIGHT_F4(pj, 1)], l2 = sc.lights[RT_LIGHT_F4(pj, 2)],
+                             l3 = sc.lights[RT_LIGHT_F4(pj, 3)];
                 if (STATS) { cn.lights++; cn.dev_lights++; }
                 pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x),
                                       mk(l2.y, l2.z, l2.w), l3.x) / (float)sc.n_lights;
@@ -1351,9 +1341,9 @@ template <bool STATS>
 __device__ __forceinline__ float light_pdf_loop(const Scene& sc, f3 hitPos, f3 outgoing, Counters& cn) {
     float pdf_light = 0.0f;
     for (int i = 0; i < sc.n_lights; i++) {
-        const int pj = load_uniform_i(sc.light_place + i);
-        const float4 l0 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 0)), l1 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 1)),
-                     l2 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 2)), l3 = load_uniform_f4(sc.lights + RT_LIGHT_F4(pj, 3));
+        const int pj = sc.light_place[i];
+        const float4 l0 = sc.lights[RT_LIGHT_F4(pj, 0)], l1 = sc.lights[RT_LIGHT_F4(pj, 1)], l2 = sc.lights[RT_LIGHT_F4(pj, 2)],
+                     l3 = sc.lights[RT_LIGHT_F4(pj, 3)];
         if (STATS) { cn.lights++; cn.dev_lights++; }
         pdf_light += itri_pdf(hitPos, outgoing, mk(l0.x, l0.y, l0.z), mk(l0.w, l1.x, l1.y), mk(l1.z, l1.w, l2.x), mk(l2.y, l2.z, l2.w), l3.x) /
                      (float)sc.n_lights;
