@@ -2685,6 +2685,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         for (int j = 0; j < nl; j++) lid[(size_t)j] = j;
         std::vector<ShortNode> lnodes;
         lnodes.reserve((size_t)nl);
+        const bool light_sah = !getenv("RT_LIGHT_TREE_MEDIAN");  // (experiments: median splits of the centroids along the widest axis)
         // returns the entry over lid[lo, hi) (>= 0: node in lnodes; < 0: ~(2 * place of the light's item)) and its padded box
         auto build_light = [&](auto&& self, int lo, int hi, float* box) -> int {
             float u[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f}, cmn[3] = {3e38f, 3e38f, 3e38f}, cmx[3] = {-3e38f, -3e38f, -3e38f};
@@ -2700,7 +2701,38 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             int axis = 0;
             for (int c = 1; c < 3; c++)
                 if (cmx[c] - cmn[c] > cmx[axis] - cmn[axis]) axis = c;
-            const int mid = lo + (hi - lo) / 2;
+            int mid = lo + (hi - lo) / 2;
+            const int n = hi - lo;
+            if (light_sah && n > 2) {
+                // surface-area split: an all-hits query visits a node whenever the ray meets its box, i.e. in proportion to the box's
+                // area, and nothing is ever pruned by distance -- the sum of the children's areas weighted by what hangs below them is
+                // exactly what a query pays.  Full sweep over the three axes (a few hundred lights: nothing).
+                float best = 3e38f;
+                int best_axis = -1, best_k = -1;
+                std::vector<int> ord((size_t)n);
+                std::vector<float> suf((size_t)n + 1);
+                for (int c = 0; c < 3; c++) {
+                    for (int k = 0; k < n; k++) ord[(size_t)k] = lid[(size_t)(lo + k)];
+                    std::sort(ord.begin(), ord.end(), [&](int a, int b) {
+                        const float ca = lb[(size_t)a][(size_t)(6 + c)], cb = lb[(size_t)b][(size_t)(6 + c)];
+                        return ca < cb || (ca == cb && a < b);
+                    });
+                    float bx[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+                    for (int k = n - 1; k >= 1; k--) {
+                        const auto& b = lb[(size_t)ord[(size_t)k]];
+                        for (int a = 0; a < 3; a++) { bx[a] = std::min(bx[a], b[(size_t)a]); bx[3 + a] = std::max(bx[3 + a], b[(size_t)(3 + a)]); }
+                        suf[(size_t)k] = half_area(bx);
+                    }
+                    float bl[6] = {3e38f, 3e38f, 3e38f, -3e38f, -3e38f, -3e38f};
+                    for (int k = 1; k < n; k++) {
+                        const auto& b = lb[(size_t)ord[(size_t)k - 1]];
+                        for (int a = 0; a < 3; a++) { bl[a] = std::min(bl[a], b[(size_t)a]); bl[3 + a] = std::max(bl[3 + a], b[(size_t)(3 + a)]); }
+                        const float cst = half_area(bl) * (float)k + suf[(size_t)k] * (float)(n - k);
+                        if (cst < best) { best = cst; best_axis = c; best_k = k; }
+                    }
+                }
+                if (best_axis >= 0) { axis = best_axis; mid = lo + best_k; }
+            }
             std::nth_element(lid.begin() + lo, lid.begin() + mid, lid.begin() + hi, [&](int a, int b) {
                 const float ca = lb[(size_t)a][(size_t)(6 + axis)], cb = lb[(size_t)b][(size_t)(6 + axis)];
                 return ca < cb || (ca == cb && a < b);
