@@ -7,5 +7,5 @@ for cfg in "$@"; do
   echo "== $cfg"
   tools/round_profile.sh $cfg $TAG > gpurun_out/round_profile_$cfg.txt 2>&1 || { tail -5 gpurun_out/round_profile_$cfg.txt; exit 1; }
   tail -1 gpurun_out/round_profile_$cfg.txt | cut -c1-400
-  cp profiles/${TAG}_bench_$cfg.json profiles/${TAG}_kernel_stats_$cfg.csv gpurun_out/profiles_new/ && cp profiles/${TAG}_pmc_*.json gpurun_out/profiles_new/
+  cp profiles/${TAG}_bench_$cfg.json profiles/${TAG}_kernel_stats_$cfg.csv gpurun_out/profiles_new/ && cp $(python3 -c "import json; print(json.load(open(\"profiles/${TAG}_bench_$cfg.json\"))[\"roofline\"][\"pmc\"][\"file\"])") gpurun_out/profiles_new/
 done
