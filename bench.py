@@ -322,7 +322,10 @@ def main():
                 roof["valu"] = {"wave_insts_per_launch": insts, "lane_ops_per_launch": lane_ops,
                                 "issue_util": round(issue_util, 4), "lane_util": round(lane_util, 4),
                                 "achieved_Tlaneops": round(lane_ops / launch_s / 1e12, 3), "peak_Tlaneops": round(VALU_PEAK_TLANEOPS, 2),
-                                "frac": round(issue_util * lane_util, 4)}
+                                "frac": round(issue_util * lane_util, 4),
+                                # what four waves per SIMD (this kernel's occupancy) were measured to reach on plain f32 instructions:
+                                # 2.36 cycles per wave-instruction (profiles/r02_valu_peak.txt), against the nominal 2 of `issue_util`
+                                "issue_util_of_4wave_peak": round(issue_util * 2.36 / VALU_CYCLES_PER_WAVE_INST, 4)}
                 fracs["valu"] = issue_util * lane_util
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0   # KB; gfx950: FETCH_SIZE counts half (MI355X_MICROARCH.md)
