@@ -756,7 +756,9 @@ __device__ __forceinline__ void trav_step_wide(const Scene& sc, Trav& t, int* st
     // pieces that is follows from the sign of the ray's direction (Trav::sgx..): the addresses differ, not the arithmetic.
     float4 a0, a1, a2, a3, b0, b1, b2;
     const int rel = t.cur - cache_base;
-    if (ALL_CACHED || (unsigned)rel < (unsigned)(n_cached - 1)) {
+    // (both items of the node inside the window; an EMPTY window -- n_cached = 0: RT_LDS_NODES=0, or an LDS that the stacks fill -- must
+    // not wrap the bound around: every node then comes from device memory)
+    if (ALL_CACHED || (unsigned)rel < (unsigned)max(n_cached - 1, 0)) {
         if (STATS) cn.dev_cached += 2;
         typedef float v4f __attribute__((ext_vector_type(4)));
         typedef const volatile __attribute__((address_space(3))) v4f* lds_v4f;

@@ -309,6 +309,29 @@ def test_sample_chunks_of_the_path_kernel(ob, rt, gpu, scenes, monkeypatch):
     gpu.reset(); gpu.render(ql); ql.sample_begin = 20; gpu.render(ql)
     assert np.array_equal(two, gpu.readback())
 
+@pytest.mark.parametrize("name", ["scene.txt", "scene2.txt", "scene2_is.txt"])
+def test_lds_window_size_changes_nothing(ob, rt, gpu, scenes, monkeypatch, name):
+    """The shortcut walk reads a wide node from the LDS window where it lies inside it and from device memory where it
+    does not (csrc/rt_device.h, trav_step_wide; the window holds compact 112-byte records of wide nodes in the scenes
+    without light queries, padded items in the others).  Whatever the window holds -- nothing, one node, an odd cut
+    through the tree, as much as fits -- the sums are the same bit for bit, and they are the oracle's."""
+    sc = scenes(name)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=4, width=160, height=90, flags=rt.F_DEFAULT)
+    images = []
+    for cap in (None, "0", "1", "2", "77", "300", "1001"):
+        if cap is None:
+            monkeypatch.delenv("RT_LDS_NODES", raising=False)
+        else:
+            monkeypatch.setenv("RT_LDS_NODES", cap)       # (read by every render call: trace_cfg)
+        gpu.reset(); gpu.render(p, want_stats=False); images.append(gpu.readback())
+    monkeypatch.delenv("RT_LDS_NODES", raising=False)
+    for img in images[1:]:
+        assert np.array_equal(images[0], img)
+    o, _ = ob.render(sc, p, n_threads=8)
+    assert np.array_equal(images[0], o)
+
+
 
 @pytest.mark.parametrize("depth", [2, 5, 8])
 def test_big_leaves_get_sub_trees(ob, rt, gpu, depth):
