@@ -309,6 +309,21 @@ def test_sample_chunks_of_the_path_kernel(ob, rt, gpu, scenes, monkeypatch):
     gpu.reset(); gpu.render(ql); ql.sample_begin = 20; gpu.render(ql)
     assert np.array_equal(two, gpu.readback())
 
+@pytest.mark.parametrize("name", ["scene.txt", "scene_cornellbox.txt", "scene2_is.txt"])
+def test_material_table_in_device_memory(rt, gpu, scenes, monkeypatch, name):
+    """A scene with more than 128 materials keeps its material table in device memory instead of the LDS (trace_cfg,
+    RT_LDS_MATS_MAX); RT_NO_LDS_MATS forces that path on the bundled scenes: same sums bit for bit."""
+    sc = scenes(name)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=4, width=160, height=90, flags=rt.F_DEFAULT)
+    monkeypatch.delenv("RT_NO_LDS_MATS", raising=False)
+    gpu.reset(); gpu.render(p, want_stats=False); in_lds = gpu.readback()
+    monkeypatch.setenv("RT_NO_LDS_MATS", "1")
+    gpu.reset(); gpu.render(p, want_stats=False); in_mem = gpu.readback()
+    monkeypatch.delenv("RT_NO_LDS_MATS")
+    assert np.array_equal(in_lds, in_mem)
+
+
 @pytest.mark.parametrize("name", ["scene.txt", "scene2.txt", "scene2_is.txt"])
 def test_lds_window_size_changes_nothing(ob, rt, gpu, scenes, monkeypatch, name):
     """The shortcut walk reads a wide node from the LDS window where it lies inside it and from device memory where it
