@@ -44,6 +44,31 @@ def test_struct_layouts_match_reference_sizes(rt):
     assert C.sizeof(rt.Camera) == 80
 
 
+def test_headers_are_plain_c_and_agree_with_the_python_mirror(rt, tmp_path):
+    """include/rt.h and include/rt_scene.h are the drop-in boundary for a C or C++ caller: they must
+    compile as strict C99 on their own, and the structs a caller fills must have the sizes the ctypes mirror uses."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler on this machine")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "rt.h"\n#include "rt_scene.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        '    printf("%d %d %d %d %d %d %d\\n", (int)sizeof(rt_render_params), (int)sizeof(rt_render_stats), (int)sizeof(rt_layout_info),\n'
+        "           (int)sizeof(rt_bvh_node), (int)sizeof(rt_material), (int)sizeof(rt_camera), RT_ABI_VERSION);\n"
+        "    return 0;\n}\n")
+    exe = tmp_path / "abi"
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes[:6] == [C.sizeof(rt.RenderParams), C.sizeof(rt.RenderStats), C.sizeof(rt.LayoutInfo), C.sizeof(rt.BvhNode),
+                         C.sizeof(rt.Material), C.sizeof(rt.Camera)]
+    assert sizes[6] == rt.core_lib().rt_abi_version()
+
+
 def test_no_gpu_means_loud_failure(rt):
     import subprocess, sys
     # in this container (no GPU) rt_create must fail, never fall back to a CPU path
