@@ -35,6 +35,32 @@ def test_rows_partition_gathered_image_is_bit_identical(rt, gpu, scenes, n_ranks
         comm.close()
 
 
+@pytest.mark.parametrize("name", ["scene.txt", "scene2_is.txt"])
+def test_rows_and_sample_slices_on_the_default_walk(rt, gpu, scenes, name):
+    """The same two partitions WITHOUT counters, i.e. through the kernel a plain call runs (the shortcut walk, its compact
+    LDS window, the hit fetch of the vertex pass; with light queries on scene2_is.txt): rows bit-identical, sample slices
+    equal to the rank-ordered sum of the slices rendered one by one."""
+    sc = scenes(name)
+    gpu.upload(sc)
+    p = rt.default_params(sc.camera, spp=6, width=136, height=77, flags=rt.F_DEFAULT)
+    gpu.reset(); gpu.render(p, want_stats=False); one = gpu.readback()
+    parts = []
+    for r in range(3):
+        q = rt.RenderParams.from_buffer_copy(p)
+        q.sample_begin, q.sample_count = 2 * r, 2
+        gpu.reset(); gpu.render(q, want_stats=False); parts.append(gpu.readback())
+    comm = rt.Comm([0] * 3, rt.COMM_LOCAL)
+    try:
+        comm.upload(sc)
+        comm.render(p, rt.PART_ROWS, 5)
+        assert np.array_equal(comm.readback(), one)
+        comm.reset()
+        comm.render(p, rt.PART_SAMPLES)
+        assert np.array_equal(comm.readback(), (parts[0] + parts[1]) + parts[2])
+    finally:
+        comm.close()
+
+
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_sample_slices_summed_in_rank_order(rt, gpu, scenes, n_ranks):
     sc = scenes("scene_cornellbox.txt")
