@@ -22,13 +22,39 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
 
 // std::vector<float> whose resize() does not clear: record arrays of a 10M-triangle scene are 1 GB, and every element is
 // written right after the array is sized (value-initialising allocator calls only).
+// Big arrays are 2 MB-aligned and advised to use huge pages (advice only): the 10 M-triangle scene touches some 3 GB of
+// fresh memory while it is assembled, a fault per 4 KB page otherwise.  RT_NO_HUGE_PAGES=1: plain malloc.
+static void* big_alloc(size_t bytes) {
+    static const bool plain = getenv("RT_NO_HUGE_PAGES") != nullptr;
+    const size_t huge = (size_t)2 << 20;
+    bytes = std::max<size_t>(bytes, 1);
+    if (bytes < 4 * huge || plain) return malloc(bytes);
+    const size_t rounded = (bytes + huge - 1) / huge * huge;
+    void* q = aligned_alloc(huge, rounded);
+    if (q) madvise(q, rounded, MADV_HUGEPAGE);
+    return q;
+}
+template <class T> struct BigFree { void operator()(T* q) const { free(q); } };
+template <class T> using BigBuf = std::unique_ptr<T[], BigFree<T>>;  // n elements of a trivial T, not filled
+template <class T> BigBuf<T> big_buf(size_t n) {
+    void* q = big_alloc(n * sizeof(T));
+    if (!q) throw std::bad_alloc();
+    return BigBuf<T>((T*)q);
+}
 template <class T>
 struct DefaultInitAlloc : std::allocator<T> {
     template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
     using std::allocator<T>::allocator;
+    T* allocate(size_t n) {
+        void* q = big_alloc(n * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        return (T*)q;
+    }
+    void deallocate(T* q, size_t) { free(q); }
     template <class U> void construct(U* ptr) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(ptr)) U; }
     template <class U, class... A> void construct(U* ptr, A&&... a) { ::new (static_cast<void*>(ptr)) U(std::forward<A>(a)...); }
 };
@@ -497,7 +523,7 @@ int finish_bvh(const std::vector<TmpNode>& nodes, const uint32_t* ids, float* tr
         offs += o.tri_len;
         if (n.a < 0) deepest_leaf = std::max(deepest_leaf, n.depth);
     }
-    std::unique_ptr<float[]> newtris(new float[std::max<size_t>(n_floats, 1)]);  // (not zero-filled: every float is written below)
+    BigBuf<float> newtris = big_buf<float>(std::max<size_t>(n_floats, 1));  // (not zero-filled: every float is written below)
     parallel_for(nodes.size(), 64, [&](size_t k) {
         const TmpNode& n = nodes[k];
         if (n.a >= 0) return;
@@ -535,10 +561,10 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
     const bool force_single_pass = getenv("RT_BVH_SINGLE_PASS") != nullptr;  // (tests: both paths on the same input)
     const size_t chunk = chunk_max;        // (range_box below: chunk of the fold)
     // (none of these is zero-filled: every element is written before it is read)
-    std::unique_ptr<float[]> csum_mem(new float[std::max<size_t>(ntri, 1) * 3]), tbox_mem(new float[std::max<size_t>(ntri, 1) * 6]);
+    BigBuf<float> csum_mem = big_buf<float>(std::max<size_t>(ntri, 1) * 3), tbox_mem = big_buf<float>(std::max<size_t>(ntri, 1) * 6);
     float* csum = csum_mem.get();
     float* tbox = tbox_mem.get();
-    std::unique_ptr<uint32_t[]> ids_mem(new uint32_t[std::max<size_t>(ntri, 1)]), tmp_mem(new uint32_t[std::max<size_t>(ntri, 1)]);
+    BigBuf<uint32_t> ids_mem = big_buf<uint32_t>(std::max<size_t>(ntri, 1)), tmp_mem = big_buf<uint32_t>(std::max<size_t>(ntri, 1));
     uint32_t* ids = ids_mem.get();
     uint32_t* tmp = tmp_mem.get();
     std::vector<TmpNode> nodes(1);
@@ -579,7 +605,7 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
     range_box(0, (uint32_t)ntri, nodes[0].mn, nodes[0].mx);
 
     bool regrouped = false;
-    std::unique_ptr<uint32_t[]> orig_mem;
+    BigBuf<uint32_t> orig_mem;
     size_t regroup_below = (size_t)1 << 17;
     if (const char* e = getenv("RT_BVH_REGROUP")) regroup_below = (size_t)std::max(0, atoi(e));  // (0: never; tests: other thresholds)
     StageTimer* tm_split = new StageTimer("bvh: splits");
@@ -631,8 +657,8 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
             // node's data is one contiguous piece (a few MB at most) instead of a gather over its whole instance; from here
             // on the id array holds POSITIONS in that copy and `orig` leads back to the triangles
             regrouped = true;
-            std::unique_ptr<float[]> csum2(new float[ntri * 3]), tbox2(new float[ntri * 6]);
-            orig_mem.reset(new uint32_t[ntri]);
+            BigBuf<float> csum2 = big_buf<float>(ntri * 3), tbox2 = big_buf<float>(ntri * 6);
+            orig_mem = big_buf<uint32_t>(ntri);
             uint32_t* orig = orig_mem.get();
             float* c2 = csum2.get();
             float* b2 = tbox2.get();
@@ -929,7 +955,7 @@ struct rt_host_scene {
     int n_spheres = 0;
     std::vector<rt_bvh_node> nodes;
     std::vector<rt_material> mats;
-    std::vector<float> textures;
+    FloatVec textures;  // (every float is written right after the array is sized)
     std::vector<int32_t> lights;
     int bvh_depth = 0;
 };
@@ -1469,7 +1495,7 @@ int rt_scene_load(const char* scene_path, const char* asset_root, const char* en
 
     // ---- getMaterialData, sceneParser.cpp:477-517 ----
     sc->cam = P.cam;
-    std::vector<float>& pixels = sc->textures;
+    FloatVec& pixels = sc->textures;
     auto load_into_pool = [&](ATexture* t, const std::string& path, std::string& err) {
         Image img;
         if (!load_image(path, img, err)) return false;
@@ -1616,9 +1642,10 @@ int rt_scene_synth_field(const char* obj_path, int instances, uint32_t seed, con
         const int f = std::max(env_upsample, 1);
         const int W = img.w * f, H = img.h * f;
         sc->textures.resize((size_t)W * H * 3);
-        for (int y = 0; y < H; y++)
+        parallel_for((size_t)H, 16, [&](size_t y) {
             for (int x = 0; x < W; x++)
-                memcpy(&sc->textures[((size_t)y * W + x) * 3], &img.rgb[((size_t)(y / f) * img.w + x / f) * 3], 12);
+                memcpy(&sc->textures[(y * (size_t)W + (size_t)x) * 3], &img.rgb[((y / (size_t)f) * (size_t)img.w + (size_t)(x / f)) * 3], 12);
+        });
         sc->cam.env_width = W;
         sc->cam.env_height = H;
     }

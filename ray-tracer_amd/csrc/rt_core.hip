@@ -30,6 +30,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
+#include <xmmintrin.h>  // (host: the sub-tree sweep keeps a box in two SSE registers)
 
 #define RT_NO_SIZED_MACROS  // (this file DEFINES rt_render & co.; callers get them as sizeof-passing macros)
 #include "rt.h"
@@ -1536,10 +1538,58 @@ namespace {
 // leaf sub-trees, cold triangle data, decoded materials, light records with their group bounds, spheres.
 // A float array that is NOT cleared when it is sized (1.6 GB of zeroes for a 10M-triangle scene, each byte written again
 // right after): whoever sizes it writes every element.
-struct RawFloats {
-    std::unique_ptr<float[]> p;
+// Big host arrays come from here: 2 MB-aligned and advised to use huge pages (advice only: refused or unsupported changes
+// nothing).  The 10 M-triangle scene touches some 4 GB of fresh host memory while its layout is built; with 4 KB pages
+// that is a million first-touch faults (measured on the item stream alone: 58 -> 34 ms).  RT_NO_HUGE_PAGES=1: plain malloc.
+static void* host_big_alloc(size_t bytes) {
+    static const bool plain = getenv("RT_NO_HUGE_PAGES") != nullptr;
+    const size_t huge = (size_t)2 << 20;
+    bytes = std::max<size_t>(bytes, 1);
+    if (bytes < 4 * huge || plain) return malloc(bytes);
+    const size_t rounded = (bytes + huge - 1) / huge * huge;
+    void* q = aligned_alloc(huge, rounded);
+    if (q) madvise(q, rounded, MADV_HUGEPAGE);
+    return q;
+}
+extern "C++" {
+template <class T>
+struct HostHuge {  // allocator of BigVec<T>
+    using value_type = T;
+    HostHuge() = default;
+    template <class U> HostHuge(const HostHuge<U>&) {}
+    T* allocate(size_t n) {
+        void* q = host_big_alloc(n * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        return (T*)q;
+    }
+    void deallocate(T* q, size_t) { free(q); }
+    template <class U> bool operator==(const HostHuge<U>&) const { return true; }
+    template <class U> bool operator!=(const HostHuge<U>&) const { return false; }
+};
+// ... and of RawVec<T>: elements of a trivial T are left as they come (no fill when the vector is sized)
+template <class T>
+struct HostRaw : HostHuge<T> {
+    HostRaw() = default;
+    template <class U> HostRaw(const HostRaw<U>&) {}
+    template <class U> struct rebind { using other = HostRaw<U>; };
+    template <class U, class... A>
+    void construct(U* q, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)q) U;
+        else ::new ((void*)q) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using BigVec = std::vector<T, HostHuge<T>>;
+template <class T> using RawVec = std::vector<T, HostRaw<T>>;
+}
+struct RawFloats {  // floats that are sized without a fill
+    struct Free { void operator()(float* q) const { free(q); } };
+    std::unique_ptr<float[], Free> p;
     size_t n = 0;
-    void size_to(size_t count) { p.reset(new float[count]); n = count; }
+    void size_to(size_t count) {
+        p.reset((float*)host_big_alloc(count * sizeof(float)));
+        if (!p) throw std::bad_alloc();
+        n = count;
+    }
     float* data() { return p.get(); }
     const float* data() const { return p.get(); }
     size_t size() const { return n; }
@@ -1548,7 +1598,7 @@ struct RawFloats {
 struct HostLayout {
     RawFloats items, cold;
     std::vector<float> mats, lights, spheres;
-    std::vector<int> place;  // reference triangle id -> place in the item stream
+    RawVec<int> place;  // reference triangle id -> place in the item stream (sized without a fill: every triangle has a place)
     std::vector<float> ref_boxes;  // the reference's node boxes as uploaded, 8 floats per node (the shortcut tree's certificate reads the leaf's)
     int n_inner = 0, n_sub = 0, n_tris = 0, root_entry = RT_TRAV_DONE, depth = 0;
     bool short_runs = false, short_single = false;
@@ -1676,12 +1726,16 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         float box[2][6]; int e[2]; int cnt;
         SubNode() {}  // (no zero-fill when the merged vector of millions of them is sized: every element is written)
     };
-    std::vector<int> at((size_t)std::max(ntri, 1));  // place -> triangle
-    std::vector<int> leaf_end((size_t)std::max(ntri, 1), 0), sub_root((size_t)std::max(nn, 1), -1);
-    std::vector<int> leaf_node((size_t)std::max(ntri, 1), 0);  // place -> the reference leaf (node index) that holds it
-    std::vector<unsigned char> tflags((size_t)std::max(ntri, 1), 0);
-    std::vector<char> covered((size_t)std::max(ntri, 1), 0);
-    for (int i = 0; i < ntri; i++) at[(size_t)i] = i;
+    // Per-triangle arrays are sized WITHOUT a fill (HostRaw): the area pass below writes their first values on all host
+    // threads (one thread's fill of 170 MB, and its page faults, were a fifth of that stage for 10 M triangles).
+    const size_t ntri1 = (size_t)std::max(ntri, 1);
+    RawVec<int> at(ntri1);  // place -> triangle
+    RawVec<int> leaf_end(ntri1);
+    RawVec<int> leaf_node(ntri1);  // place -> the reference leaf (node index) that holds it
+    RawVec<unsigned char> tflags(ntri1);
+    std::vector<int> sub_root((size_t)std::max(nn, 1), -1);
+    at[0] = leaf_end[0] = leaf_node[0] = 0;
+    tflags[0] = 0;
     auto centroid = [&](int tri, int k) {
         const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
         return (t[k] + t[3 + k] + t[6 + k]) * (1.0f / 3.0f);
@@ -1700,7 +1754,8 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     // chance that a ray which reaches a node's box reaches a child's: the ratio of the surface areas, plus the share
     // of all rays that START on a triangle of the child (every bounce does, and then the child's box is reached for
     // sure: what makes sub-trees over wall-sized triangles a loss)
-    std::vector<float> tri_area((size_t)std::max(ntri, 1), 0.f);
+    RawVec<float> tri_area(ntri1);
+    tri_area[0] = 0.f;
     double total_area = 0.0;
     float scene_scale = 0.f;  // largest |coordinate| of the scene
     int n_workers_max = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -1720,6 +1775,9 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     const H3 e1{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
                     tri_area[i] = 0.5f * hlen(hcross(e1, e2));
                     a += tri_area[i];
+                    at[i] = (int)i;
+                    leaf_end[i] = leaf_node[i] = 0;  // (a triangle outside every leaf keeps these)
+                    tflags[i] = 0;
                 }
                 part_area[c] = a;
                 part_scale[c] = sc_max;
@@ -1768,39 +1826,55 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     // Per-triangle centroids are not needed after the sort; boxes and areas sit in small local arrays.
     auto sweep_sub = [&](auto&& self, SubWork& w, int lo, int hi, int d, float* box, bool root) -> int {
         const int n = hi - lo, o = lo - w.base;
-        float tight[6];
-        memcpy(tight, kEmpty, sizeof(tight));
+        // A box lives in two SSE registers (mins, maxs; the fourth lane stays 0): the same min / max / subtract / multiply /
+        // add per component as the scalar form of build_sub below, in the same order -- the same floats, a third of the
+        // instructions on the sweep's dependent chains.
+        const __m128 empty_lo = _mm_setr_ps(3e38f, 3e38f, 3e38f, 0.f), empty_hi = _mm_setr_ps(-3e38f, -3e38f, -3e38f, 0.f);
+        auto half_area4 = [](__m128 mn, __m128 mx) {  // x * y + y * z + z * x of the extents, summed left to right
+            const __m128 e = _mm_sub_ps(mx, mn);
+            const __m128 p = _mm_mul_ps(e, _mm_shuffle_ps(e, e, _MM_SHUFFLE(3, 0, 2, 1)));  // (xy, yz, zx, 0)
+            return _mm_cvtss_f32(_mm_add_ss(_mm_add_ss(p, _mm_shuffle_ps(p, p, 1)), _mm_shuffle_ps(p, p, 2)));
+        };
+        const float* lb = w.lbox.data();
+        __m128 tlo = empty_lo, thi = empty_hi;
         for (int k = 0; k < n; k++) {
-            const float* b = &w.lbox[6 * (size_t)w.ord[0][(size_t)(o + k)]];
-            for (int c = 0; c < 3; c++) { tight[c] = std::min(tight[c], b[c]); tight[3 + c] = std::max(tight[3 + c], b[3 + c]); }
+            const float* b = lb + 8 * (size_t)w.ord[0][(size_t)(o + k)];
+            tlo = _mm_min_ps(_mm_loadu_ps(b), tlo);  // (min_ps(a, b) = a < b ? a : b: std::min(tight, b) with its operands swapped)
+            thi = _mm_max_ps(_mm_loadu_ps(b + 4), thi);
         }
-        memcpy(box, tight, sizeof(tight));
+        float t_lo[4], t_hi[4];
+        _mm_storeu_ps(t_lo, tlo);
+        _mm_storeu_ps(t_hi, thi);
+        for (int k = 0; k < 3; k++) { box[k] = t_lo[k]; box[3 + k] = t_hi[k]; }
         for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
         w.deepest = std::max(w.deepest, d);
         w.leaf_deepest = std::max(w.leaf_deepest, d);
         int mid = -1;
-        const float pa = half_area(tight);
+        const float pa = half_area4(tlo, thi);
         if (n >= 2 && d < RT_STACK_ENTRIES && pa > 0.f) {
             float best = 3e38f;  // expected triangle tests below this node if it is split
             int best_axis = -1, best_k = -1;
             for (int axis = 0; axis < 3; axis++) {
                 const int* so = &w.ord[axis][(size_t)o];
-                float bx[6], ar = 0.f;
-                memcpy(bx, kEmpty, sizeof(bx));
+                __m128 blo = empty_lo, bhi = empty_hi;
+                float ar = 0.f;
                 for (int k = n - 1; k >= 1; k--) {  // box area and triangle area of so[k..n)
-                    const float* b = &w.lbox[6 * (size_t)so[k]];
-                    for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], b[c]); bx[3 + c] = std::max(bx[3 + c], b[3 + c]); }
+                    const float* b = lb + 8 * (size_t)so[k];
+                    blo = _mm_min_ps(_mm_loadu_ps(b), blo);
+                    bhi = _mm_max_ps(_mm_loadu_ps(b + 4), bhi);
                     ar += w.larea[(size_t)so[k]];
-                    w.suffix[2 * (size_t)k] = half_area(bx);
+                    w.suffix[2 * (size_t)k] = half_area4(blo, bhi);
                     w.suffix[2 * (size_t)k + 1] = ar;
                 }
-                memcpy(bx, kEmpty, sizeof(bx));
+                blo = empty_lo;
+                bhi = empty_hi;
                 ar = 0.f;
                 for (int k = 1; k < n; k++) {  // left = the first k
-                    const float* b = &w.lbox[6 * (size_t)so[k - 1]];
-                    for (int c = 0; c < 3; c++) { bx[c] = std::min(bx[c], b[c]); bx[3 + c] = std::max(bx[3 + c], b[3 + c]); }
+                    const float* b = lb + 8 * (size_t)so[k - 1];
+                    blo = _mm_min_ps(_mm_loadu_ps(b), blo);
+                    bhi = _mm_max_ps(_mm_loadu_ps(b + 4), bhi);
                     ar += w.larea[(size_t)so[k - 1]];
-                    const float cst = std::min(1.f, half_area(bx) / pa + ar * inv_total_area) * (float)k +
+                    const float cst = std::min(1.f, half_area4(blo, bhi) / pa + ar * inv_total_area) * (float)k +
                                       std::min(1.f, w.suffix[2 * (size_t)k] / pa + w.suffix[2 * (size_t)k + 1] * inv_total_area) * (float)(n - k);
                     if (cst < best) { best = cst; best_axis = axis; best_k = k; }
                 }
@@ -1851,7 +1925,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         const int n = hi - lo;
         w.base = lo;
         w.ltri.resize((size_t)n);
-        w.lbox.resize(6 * (size_t)n);
+        w.lbox.resize(8 * (size_t)n);  // per triangle: mins, 0, maxs, 0
         w.larea.resize((size_t)n);
         w.side.resize((size_t)n);
         w.scratch.resize((size_t)n);
@@ -1862,9 +1936,12 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         if (!std::is_sorted(w.ltri.begin(), w.ltri.end())) std::sort(w.ltri.begin(), w.ltri.end());
         for (int k = 0; k < n; k++) {
             const int tri = w.ltri[(size_t)k];
-            float* b = &w.lbox[6 * (size_t)k];
-            memcpy(b, kEmpty, 6 * sizeof(float));
-            grow(b, tri);
+            float b6[6];
+            memcpy(b6, kEmpty, sizeof(b6));
+            grow(b6, tri);
+            float* b = &w.lbox[8 * (size_t)k];
+            b[0] = b6[0]; b[1] = b6[1]; b[2] = b6[2]; b[3] = 0.f;
+            b[4] = b6[3]; b[5] = b6[4]; b[6] = b6[5]; b[7] = 0.f;
             w.larea[(size_t)k] = tri_area[(size_t)tri];
         }
         for (int axis = 0; axis < 3; axis++) {
@@ -1984,23 +2061,55 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         return idx;
     };
     std::vector<int> candidates;
-    for (int i = 0; i < nn; i++) {
-        const rt_bvh_node& n = s->nodes[i];
-        if (n.child_a != -1) continue;
-        const int first = n.tri_offs / RT_TRI_FLOATS, cnt = n.tri_len / RT_TRI_FLOATS;
-        for (int k = 0; k < cnt; k++) {
-            // a triangle in two leaves would need two "last" flags: the reference builder never does that
-            if (covered[(size_t)first + k]) return fail(RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
-            covered[(size_t)first + k] = 1;
-            tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
-            leaf_end[(size_t)first + k] = first + cnt;
-            leaf_node[(size_t)first + k] = i;
+    {
+        std::vector<int> leaves;  // (node indices; then sorted by their first triangle)
+        for (int i = 0; i < nn; i++) {
+            const rt_bvh_node& n = s->nodes[i];
+            if (n.child_a != -1) continue;
+            if (n.tri_len > 0) leaves.push_back(i);
+            // (the traversal stack must have room below this leaf)
+            if (n.tri_len / RT_TRI_FLOATS >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
         }
-        // (the traversal stack must have room below this leaf)
-        if (cnt >= big_leaf && ntri >= sub_min_tris && depth[i] < RT_STACK_ENTRIES) candidates.push_back(i);
+        auto by_first = [&](int a, int b) { return s->nodes[a].tri_offs < s->nodes[b].tri_offs; };
+        if (!std::is_sorted(leaves.begin(), leaves.end(), by_first)) std::sort(leaves.begin(), leaves.end(), by_first);
+        // a triangle in two leaves would need two "last" flags: the reference builder never does that
+        for (size_t k = 1; k < leaves.size(); k++)
+            if (s->nodes[leaves[k]].tri_offs < s->nodes[leaves[k - 1]].tri_offs + s->nodes[leaves[k - 1]].tri_len)
+                return fail(RT_ERR_INVALID, "BVH leaves overlap in the triangle array");
+        // the leaves' ranges are disjoint: their flags are written by all host threads, a contiguous run of leaves each
+        const int nw = leaves.size() >= 4096 ? n_workers_max : 1;
+        auto fill = [&](int wi) {
+            for (size_t li = leaves.size() * (size_t)wi / (size_t)nw; li < leaves.size() * (size_t)(wi + 1) / (size_t)nw; li++) {
+                const int i = leaves[li];
+                const int first = s->nodes[i].tri_offs / RT_TRI_FLOATS, cnt = s->nodes[i].tri_len / RT_TRI_FLOATS;
+                for (int k = 0; k < cnt; k++) {
+                    tflags[(size_t)first + k] = (unsigned char)((k == cnt - 1 ? 1 : 0) | (k == 0 ? 2 : 0));
+                    leaf_end[(size_t)first + k] = first + cnt;
+                    leaf_node[(size_t)first + k] = i;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int wi = 1; wi < nw; wi++) th.emplace_back(fill, wi);
+        fill(0);
+        for (auto& t : th) t.join();
     }
     timer.stage("areas, flags, candidates");
-    const int n_workers = candidates.size() >= 4096 ? n_workers_max : 1;
+    // The candidates are cut into n_workers contiguous PARTS (a fixed number: the result does not depend on the thread
+    // count), several per host thread, and the threads take parts as they come free: leaves differ in cost, and with one
+    // part per thread the slowest thread took 1.15 x the mean.
+    const int n_threads = candidates.size() >= 4096 ? n_workers_max : 1;
+    const int n_workers = candidates.size() >= 4096 ? 128 : 1;
+    auto run_parts = [&](auto&& fn) {
+        std::atomic<int> next{0};
+        auto body = [&] {
+            for (int wi; (wi = next.fetch_add(1)) < n_workers;) fn(wi);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; t++) th.emplace_back(body);
+        body();
+        for (auto& t : th) t.join();
+    };
     std::vector<SubWork> work((size_t)n_workers);
     {
         auto run = [&](int wi) {
@@ -2021,10 +2130,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 }
             }
         };
-        std::vector<std::thread> th;
-        for (int wi = 1; wi < n_workers; wi++) th.emplace_back(run, wi);
-        run(0);
-        for (auto& t : th) t.join();
+        run_parts(run);
     }
     timer.stage("sub-tree build (threads)");
     // fn(chunk, lo, hi) over [0, n) cut into n_workers_max ranges, one host thread each (one range when n is small)
@@ -2036,7 +2142,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         for (auto& t : th) t.join();
         return nw;
     };
-    std::vector<SubNode> subs;  // the workers' nodes one after the other (contiguous leaf ranges: same order as one thread's)
+    BigVec<SubNode> subs;  // the workers' nodes one after the other (contiguous leaf ranges: same order as one thread's)
     int deepest = max_depth;    // of the whole structure: sizes the traversal stack
     {
         std::vector<size_t> off((size_t)n_workers + 1, 0);
@@ -2052,10 +2158,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 subs[(size_t)o + k] = nd;
             }
         };
-        std::vector<std::thread> th;
-        for (int wi = 1; wi < n_workers; wi++) th.emplace_back(copy, wi);
-        copy(0);
-        for (auto& t : th) t.join();
+        run_parts(copy);
         for (int wi = 0; wi < n_workers; wi++) {
             for (const auto& r : work[(size_t)wi].roots) sub_root[(size_t)r.first] = (int)off[(size_t)wi] + r.second;
             deepest = std::max(deepest, work[(size_t)wi].deepest);
@@ -2161,7 +2264,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     //      Needs the reference's boxes to be nested (child inside parent), as its builder makes them.
     struct ShortPrim { float b[6]; float c[3]; float cost; int node; };
     struct ShortNode { float box[2][6]; int e[2]; };  // e >= 0: shortcut node, e < 0: ~(ShortPrim::node of what hangs there)
-    std::vector<ShortNode> shorts;
+    BigVec<ShortNode> shorts;
     int short_root = -1, short_levels = 0, below_leaf = 0;
     bool short_runs = false, short_single = false;
     int short_cut = 0;  // levels below the reference's leaves at which the shortcut tree's own leaves stand (when it is not over runs)
@@ -2181,7 +2284,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         // What hangs below the shortcut tree: the RUNS of the item stream -- triangles tested one after the other up to a
         // 'last' flag: a sub-leaf, or a whole reference leaf without a sub-tree -- so that the walk never enters a sub-tree;
         // in a scene with more than RT_SHORT_RUNS_MAX of them the reference's leaves with their sub-trees (a smaller build).
-        std::vector<ShortPrim> prims;
+        BigVec<ShortPrim> prims;
         if (want) {
             size_t runs_max = RT_SHORT_RUNS_MAX;
             if (const char* e = getenv("RT_SHORT_RUNS_MAX")) runs_max = (size_t)atoll(e);  // experiments only
@@ -2221,7 +2324,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             };
             if (short_runs) {
                 prims.resize(c_runs[(size_t)nr]);
-                std::vector<int> run_src;  // place of a sub-leaf's first triangle -> 2 * sub node + side
+                BigVec<int> run_src;  // place of a sub-leaf's first triangle -> 2 * sub node + side
                 if (n_sub > 0) {
                     run_src.assign((size_t)ntri, -1);
                     par_ranges((size_t)n_sub, [&](int, size_t lo, size_t hi) {
@@ -2534,7 +2637,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         float box[4][6]; int e[4]; int nk;
         WideNode() {}  // (no zero-fill when a vector of millions of them is sized: whoever sizes it writes every element)
     };
-    std::vector<WideNode> wides;
+    BigVec<WideNode> wides;
     int wide_root = -1, wide_need = 0;  // (stack entries a search of the wide tree can need: sum of (children - 1) down the worst path)
     int n_wide_top = 0;                 // wide nodes of the shortcut tree proper (the others: wide forms of sub-tree parts, huge scenes)
     timer.stage("shortcut tree: two-child build");
@@ -2591,7 +2694,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     const int e = wides[(size_t)w].e[i];
                     if (e < 0 && (~e & 1)) tasks.push_back({w, i, ~e >> 1});
                 }
-            auto collapse_sub = [&](auto&& self, std::vector<WideNode>& out, int bnode, int& need) -> int {
+            auto collapse_sub = [&](auto&& self, auto& out, int bnode, int& need) -> int {
                 const float* kbox[4];
                 int ke[4], nk = 2;
                 kbox[0] = subs[(size_t)bnode].box[0]; ke[0] = subs[(size_t)bnode].e[0];
@@ -2798,7 +2901,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     // random ray meets a box in proportion to its area, and the LDS node cache of the kernels holds the items from the
     // front.  Behind them the reference's BFS order and the sub-trees' depth-first order stay as they are, which keeps
     // neighbours in the tree close in memory.  "Node q" below: q < nn is the reference's node q, q >= nn sub-tree node q - nn.
-    std::vector<int> sub_index((size_t)std::max(n_sub, 1), 0), short_index((size_t)std::max(n_short, 1), 0), wide_index;
+    BigVec<int> sub_index((size_t)std::max(n_sub, 1), 0), short_index((size_t)std::max(n_short, 1), 0), wide_index;
     int short_base = 0;
     {
         struct Key { float area; int kind, id; };
@@ -2903,7 +3006,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             big = select(1 | 2 | 4, front);
         }
         if (n_wide == 0) rest_base = big.size();
-        std::vector<char> taken(std::max<size_t>(nq, 1), 0);
+        BigVec<char> taken(std::max<size_t>(nq, 1), 0);
         for (size_t k = 0; k < big.size(); k++) {
             const Key& b = big[k];
             taken[b.kind == 0 ? (size_t)b.id : (b.kind == 1 ? (size_t)nn + (size_t)b.id : (size_t)nn + (size_t)n_sub + (size_t)b.id)] = 1;
@@ -2944,10 +3047,11 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     timer.stage("merge, order");
     RawFloats& items = L.items;
     RawFloats& cold = L.cold;
-    std::vector<int>& place = L.place;
+    RawVec<int>& place = L.place;
     items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1 + (size_t)n_light_items) * 16);  // (+ one item of padding behind the last triangle, then the light items)
     if (!early) cold.size_to((size_t)std::max(ntri, 1) * 16);  // (early: the other thread sizes, fills and uploads it)
-    place.assign((size_t)std::max(ntri, 1), 0);
+    place.resize((size_t)std::max(ntri, 1));
+    place[0] = 0;  // (no triangles: one entry, defined)
     for (int k = 0; k < 16; k++) items[((size_t)n_inner + (size_t)ntri) * 16 + (size_t)k] = 0.f;
     if (ntri == 0 && !early)
         for (int k = 0; k < 16; k++) cold[(size_t)k] = 0.f;
