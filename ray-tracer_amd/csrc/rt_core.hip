@@ -1612,6 +1612,17 @@ struct HostLayout {
 
 // What does not depend on the layout -- the cold triangle data (the reference's order) and the texture pool, 45 % of a big scene's
 // bytes -- is formed and copied to the device by a thread of its own WHILE build_layout runs (rt_upload_scene only).
+// The item of the triangle at place p of the item stream (rt_device.h): vertex 0, the two edges, flags, end of its leaf, id, leaf.
+static inline void fill_tri_item(float* h, const float* tris, int tri, unsigned char flags, int leaf_end, int leaf_node) {
+    const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
+    h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
+    h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
+    h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
+    h[9] = i2f((int)flags); h[10] = i2f(leaf_end); h[11] = i2f(tri);
+    h[12] = i2f(leaf_node);
+    h[13] = h[14] = h[15] = 0.f;
+}
+
 struct EarlyUpload {
     rt_context* c = nullptr;
     std::thread th;
@@ -1620,6 +1631,33 @@ struct EarlyUpload {
     std::string err;
     void* d_cold = nullptr;
     void* d_tex = nullptr;
+    // ... and, once the triangles' order is final (after the sub-tree build), their items: written to a host array of their
+    // own and copied to a device array of their own while the shortcut tree is built; upload_built moves them into place
+    // behind the nodes' items on the device (where the nodes end is not known before the shortcut tree is)
+    std::thread th_tris;
+    RawFloats tri_items;
+    void* d_tri_items = nullptr;
+    int rc_tris = RT_OK;
+    std::string err_tris;
+    void start_tris(const float* tris, int ntri, const int* at, const unsigned char* tflags, const int* leaf_end, const int* leaf_node, int* place) {
+        th_tris = std::thread([=] {
+            auto fail = [&](const char* what, hipError_t e) { rc_tris = RT_ERR_DEVICE; err_tris = std::string(what) + ": " + hipGetErrorString(e); };
+            hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) return fail("hipSetDevice", e);
+            tri_items.size_to((size_t)ntri * 16);
+            const int nt = 4;
+            std::vector<std::thread> w;
+            auto fill = [&](int wi) {
+                for (size_t p = (size_t)ntri * (size_t)wi / (size_t)nt; p < (size_t)ntri * (size_t)(wi + 1) / (size_t)nt; p++)
+                    place[(size_t)at[p]] = (int)p, fill_tri_item(&tri_items[p * 16], tris, at[p], tflags[p], leaf_end[p], leaf_node[p]);
+            };
+            for (int wi = 1; wi < nt; wi++) w.emplace_back(fill, wi);
+            fill(0);
+            for (auto& t : w) t.join();
+            if ((e = hipMalloc(&d_tri_items, tri_items.size() * 4)) != hipSuccess) return fail("hipMalloc(triangle items)", e);
+            if ((e = hipMemcpy(d_tri_items, tri_items.data(), tri_items.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(triangle items)", e);
+        });
+    }
     void start(const rt_scene_desc* s, const float* tris, int ntri, RawFloats* cold) {
         started = true;
         th = std::thread([this, s, tris, ntri, cold] {
@@ -1651,13 +1689,16 @@ struct EarlyUpload {
     }
     int finish() {
         if (started && th.joinable()) th.join();
+        if (th_tris.joinable()) th_tris.join();
+        if (rc == RT_OK && rc_tris != RT_OK) { rc = rc_tris; err = err_tris; }
         return rc;
     }
     void discard() {  // the upload did not go through: give the early copies back
         finish();
         if (d_cold) (void)hipFree(d_cold);
         if (d_tex) (void)hipFree(d_tex);
-        d_cold = d_tex = nullptr;
+        if (d_tri_items) (void)hipFree(d_tri_items);
+        d_cold = d_tex = d_tri_items = nullptr;
     }
 };
 
@@ -2165,6 +2206,17 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         }
     }
     const int n_top = n_inner, n_sub = (int)subs.size();
+    L.place.resize((size_t)std::max(ntri, 1));
+    L.place[0] = 0;  // (no triangles: one entry, defined)
+    // the triangles' order, flags and leaves are final from here on: their items can be written and copied meanwhile
+    int early_tris_min = 1 << 20;  // (below: the thread costs more than the copy)
+    if (const char* e = getenv("RT_EARLY_TRIS_MIN")) early_tris_min = std::max(1, atoi(e));  // tests: small scenes take this way too
+    const bool early_tris = early && early->started && ntri >= early_tris_min && !getenv("RT_NO_EARLY_TRIS");
+    if (early_tris) early->start_tris(tris, ntri, at.data(), tflags.data(), leaf_end.data(), leaf_node.data(), L.place.data());
+    struct JoinTris {  // that thread reads arrays of this function: it has ended before they go, whichever way the function is left
+        EarlyUpload* e;
+        ~JoinTris() { if (e && e->th_tris.joinable()) e->th_tris.join(); }
+    } join_tris{early_tris ? early : nullptr};
     timer.stage("sub-tree nodes merged");
     // ---- lights: ImportanceTri constructor (importanceTri.h:19-25) evaluated once.  With enough lights for the
     //      wave-cooperative loop (rt_device.h) the records are stored in SPATIAL order (Morton code of the centroid), so
@@ -3050,23 +3102,14 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
     RawVec<int>& place = L.place;
     items.size_to(((size_t)n_inner + (size_t)std::max(ntri, 0) + 1 + (size_t)n_light_items) * 16);  // (+ one item of padding behind the last triangle, then the light items)
     if (!early) cold.size_to((size_t)std::max(ntri, 1) * 16);  // (early: the other thread sizes, fills and uploads it)
-    place.resize((size_t)std::max(ntri, 1));
-    place[0] = 0;  // (no triangles: one entry, defined)
     for (int k = 0; k < 16; k++) items[((size_t)n_inner + (size_t)ntri) * 16 + (size_t)k] = 0.f;
     if (ntri == 0 && !early)
         for (int k = 0; k < 16; k++) cold[(size_t)k] = 0.f;
-    par_ranges((size_t)ntri, [&](int, size_t lo, size_t hi) {
+    if (!early_tris) par_ranges((size_t)ntri, [&](int, size_t lo, size_t hi) {  // (early_tris: the other thread writes them, and `place`)
         for (size_t p = lo; p < hi; p++) {
             const int tri = at[p];
             place[(size_t)tri] = (int)p;
-            const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
-            float* h = &items[((size_t)n_inner + p) * 16];
-            h[0] = t[0]; h[1] = t[1]; h[2] = t[2];
-            h[3] = t[3] - t[0]; h[4] = t[4] - t[1]; h[5] = t[5] - t[2];   // edge1 = v1 - v0, main.cu:43
-            h[6] = t[6] - t[0]; h[7] = t[7] - t[1]; h[8] = t[8] - t[2];   // edge2 = v2 - v0, main.cu:44
-            h[9] = i2f((int)tflags[p]); h[10] = i2f(leaf_end[p]); h[11] = i2f(tri);
-            h[12] = i2f(leaf_node[p]);
-            h[13] = h[14] = h[15] = 0.f;
+            fill_tri_item(&items[((size_t)n_inner + p) * 16], tris, tri, tflags[p], leaf_end[p], leaf_node[p]);
             if (early) continue;
             const float* u = tris + p * RT_TRI_FLOATS;                    // cold data stays in the reference's order
             float* cd = &cold[p * 16];
@@ -3223,7 +3266,18 @@ static int upload_built(rt_context* c, const rt_scene_desc* s, const HostLayout&
     free_scene(c);
     if ((rc = upload_buf(c, &c->d_place, L.place.data(), L.place.size() * 4)) != RT_OK) return rc;
     if ((rc = upload_buf(c, &c->d_refboxes, L.ref_boxes.data(), L.ref_boxes.size() * 4)) != RT_OK) return rc;
-    if ((rc = upload_buf(c, &c->d_items, L.items.data(), L.items.size() * 4)) != RT_OK) return rc;
+    if (early && early->d_tri_items) {
+        // the triangles' items are on the device already: the nodes' items in front of them and what stands behind them
+        // (padding, light items) come from the host, the triangles' move into place on the device
+        const size_t tri_lo = (size_t)L.n_inner * 64, tri_hi = tri_lo + (size_t)L.n_tris * 64, total = L.items.size() * 4;
+        const char* host = (const char*)L.items.data();
+        HIP_TRY(c, hipMalloc(&c->d_items, total));
+        if (tri_lo) HIP_TRY(c, hipMemcpy(c->d_items, host, tri_lo, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy((char*)c->d_items + tri_hi, host + tri_hi, total - tri_hi, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy((char*)c->d_items + tri_lo, early->d_tri_items, tri_hi - tri_lo, hipMemcpyDeviceToDevice));
+        HIP_TRY(c, hipFree(early->d_tri_items));
+        early->d_tri_items = nullptr;
+    } else if ((rc = upload_buf(c, &c->d_items, L.items.data(), L.items.size() * 4)) != RT_OK) return rc;
     if (early) {  // (copied while the layout was built)
         c->d_cold = early->d_cold;
         c->d_tex = early->d_tex;

@@ -324,6 +324,30 @@ def test_material_table_in_device_memory(rt, gpu, scenes, monkeypatch, name):
     assert np.array_equal(in_lds, in_mem)
 
 
+@pytest.mark.parametrize("name", ["scene.txt", "scene_cornellbox.txt", "scene2_is.txt"])
+def test_upload_ways_give_the_same_scene(rt, gpu, scenes, monkeypatch, name):
+    """rt_upload_scene has three ways to bring a scene to the device (csrc/rt_core.hip): everything copied at the end
+    (RT_NO_EARLY_UPLOAD), cold data and textures copied by a thread of their own meanwhile (the default), and from a
+    million triangles on the triangles' items too, written and copied while the shortcut tree is built and moved into
+    place on the device (RT_EARLY_TRIS_MIN lowers that bound for the test).  Same sums bit for bit, stats included."""
+    sc = scenes(name)
+    p = rt.default_params(sc.camera, spp=4, width=160, height=90, flags=rt.F_DEFAULT | rt.F_STATS)
+    results = []
+    for env in ({}, {"RT_NO_EARLY_UPLOAD": "1"}, {"RT_EARLY_TRIS_MIN": "1"}, {"RT_EARLY_TRIS_MIN": "1", "RT_NO_HUGE_PAGES": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu.upload(sc)
+        for k in env:
+            monkeypatch.delenv(k)
+        gpu.reset()
+        st = gpu.render(p)
+        results.append((gpu.readback(), (st.rays, st.inner_visits, st.leaf_visits, st.tri_tests, st.dev_inner_visits, st.dev_wide_visits)))
+    for img, counts in results[1:]:
+        assert np.array_equal(results[0][0], img)
+        assert counts == results[0][1]
+    gpu.upload(sc)
+
+
 @pytest.mark.parametrize("name", ["scene.txt", "scene2.txt", "scene2_is.txt"])
 def test_lds_window_size_changes_nothing(ob, rt, gpu, scenes, monkeypatch, name):
     """The shortcut walk reads a wide node from the LDS window where it lies inside it and from device memory where it
