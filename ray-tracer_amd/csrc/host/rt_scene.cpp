@@ -638,7 +638,9 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
         // rounding is part of the result, :113-123), so the few huge nodes at the top of the tree would otherwise
         // walk their millions of triangles one node after the other
         std::vector<float> means(splitting.size());
-        parallel_for(splitting.size(), 1, [&](size_t k) {
+        // (tasks of several nodes once there are thousands: neighbours in `nodes` share cache lines, and one counter hands out the tasks)
+        const size_t node_grain = std::min<size_t>(64, std::max<size_t>(1, splitting.size() / ((size_t)host_threads() * 16)));
+        parallel_for(splitting.size(), node_grain, [&](size_t k) {
             const TmpNode& n = nodes[splitting[k]];
             const int axis = axis_of(n);
             float mean = 0.0f;
@@ -651,7 +653,7 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
         // round (or nothing big among them): one node per task, split by its thread in a single pass
         size_t biggest = 0;
         for (int ni : splitting) biggest = std::max<size_t>(biggest, nodes[ni].end - nodes[ni].begin);
-        const bool node_per_task = splitting.size() >= (size_t)host_threads() * 2 || biggest <= small_node || force_single_pass;
+        const bool node_per_task = splitting.size() >= (size_t)host_threads() || biggest <= small_node || force_single_pass;
         if (!regrouped && biggest <= regroup_below && !splitting.empty()) {
             // once the nodes are small: the per-triangle sums and boxes rewritten in the order of the id array, so that a
             // node's data is one contiguous piece (a few MB at most) instead of a gather over its whole instance; from here
@@ -757,7 +759,7 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
                 }
         };
         if (!node_per_task) for (size_t k = 0; k < splitting.size(); k++) split_one(k);
-        else parallel_for(splitting.size(), 1, split_one);
+        else parallel_for(splitting.size(), node_grain, split_one);
         level.clear();
         for (int ni : splitting) { level.push_back(nodes[ni].a); level.push_back(nodes[ni].b); }
         if (getenv("RT_SCENE_TIMING") && atoi(getenv("RT_SCENE_TIMING")) >= 2)
