@@ -2479,11 +2479,13 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             int short_sweep_max = np <= (1 << 18) ? RT_SHORT_SWEEP_MAX : 64;
             if (const char* e = getenv("RT_SHORT_SWEEP_MAX")) short_sweep_max = std::max(2, atoi(e));  // experiments only
             struct Bins { float bb[3][32][6], bw[3][32]; int bn[3][32]; float ub[6], cmn[3], cmx[3]; };
-            // A pass over prims[lo, hi) in fixed chunks of 2^16, the chunks' results folded in chunk order: the same result on
-            // any number of threads (the float sums included); big nodes only, where the recursion has few branches yet.
+            // A pass over prims[lo, hi) in fixed chunks of 2^13, the chunks' results folded in chunk order: the same result on
+            // any number of threads (the float sums included); big nodes only, where the recursion has few branches yet
+            // (from 2^15 leaves on: the 10 M-triangle field has 260 k, and its first four levels were 30 of the stage's 41 ms
+            // on one, two, four and eight threads).
             auto chunked = [&](int lo, int hi, auto&& init, auto&& one, auto&& fold, auto& total) {
-                const int CH = 1 << 16, n = hi - lo, nch = (n + CH - 1) / CH;
-                if (n < (1 << 18)) {
+                const int CH = 1 << 13, n = hi - lo, nch = (n + CH - 1) / CH;
+                if (n < (1 << 15)) {
                     init(total);
                     for (int p = lo; p < hi; p++) one(total, prims[(size_t)p]);
                     return;
@@ -2515,11 +2517,148 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     return ka < kb || (ka == kb && a.node < b.node);
                 };
             };
+            // The full sweep below a node of at most short_sweep_max leaves, as the sub-tree builder does it (sweep_sub above):
+            // the node's leaves are sorted ONCE per axis (centroid, ties by what hangs there: one 64-bit key) and a split keeps
+            // the three orders by stable partition -- the same splits as sorting the 44-byte records at every node (the form
+            // below, RT_SHORT_RESORT=1: tests), which was most of this stage for the 10 M-triangle field.
+            struct ShortSweep {
+                int base = 0;
+                std::vector<float> lb, lcost, lc, suffix;  // per local leaf: box (mins, 0, maxs, 0), cost, centroid
+                std::vector<int> lnode, ord[3], scratch;
+                std::vector<unsigned char> side;
+                std::vector<uint64_t> keys;
+            };
+            auto ckey = [](float f) {  // the float's bits made monotonic, -0 folded into +0
+                f += 0.0f;
+                uint32_t u;
+                memcpy(&u, &f, 4);
+                return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            };
+            auto sweep_short_begin = [&](ShortSweep& w, int lo, int hi) {
+                const int n = hi - lo;
+                w.base = lo;
+                w.keys.resize((size_t)n);
+                for (int k = 0; k < n; k++) w.keys[(size_t)k] = ((uint64_t)((uint32_t)prims[(size_t)(lo + k)].node ^ 0x80000000u) << 32) | (uint32_t)k;
+                std::sort(w.keys.begin(), w.keys.end());  // local index order = order of what hangs there: the index then breaks ties like it
+                w.lb.resize(8 * (size_t)n); w.lcost.resize((size_t)n); w.lc.resize(3 * (size_t)n); w.lnode.resize((size_t)n);
+                w.side.resize((size_t)n); w.scratch.resize((size_t)n); w.suffix.resize(2 * ((size_t)n + 1));
+                for (int k = 0; k < n; k++) {
+                    const ShortPrim& p = prims[(size_t)(lo + (int)(uint32_t)w.keys[(size_t)k])];
+                    float* b = &w.lb[8 * (size_t)k];
+                    b[0] = p.b[0]; b[1] = p.b[1]; b[2] = p.b[2]; b[3] = 0.f;
+                    b[4] = p.b[3]; b[5] = p.b[4]; b[6] = p.b[5]; b[7] = 0.f;
+                    w.lcost[(size_t)k] = p.cost;
+                    w.lnode[(size_t)k] = p.node;
+                    for (int c = 0; c < 3; c++) w.lc[3 * (size_t)k + (size_t)c] = p.c[c];
+                }
+                for (int axis = 0; axis < 3; axis++) {
+                    for (int k = 0; k < n; k++) w.keys[(size_t)k] = ((uint64_t)ckey(w.lc[3 * (size_t)k + (size_t)axis]) << 32) | (uint32_t)k;
+                    std::sort(w.keys.begin(), w.keys.end());
+                    w.ord[axis].resize((size_t)n);
+                    for (int k = 0; k < n; k++) w.ord[axis][(size_t)k] = (int)(uint32_t)w.keys[(size_t)k];
+                }
+            };
+            auto sweep_short = [&](auto&& self, ShortSweep& w, int lo, int hi, int d, float* box) -> int {
+                const int n = hi - lo, o = lo - w.base;
+                int seen = deepest_short.load();
+                while (seen < d && !deepest_short.compare_exchange_weak(seen, d)) {}
+                if (n == 1) {
+                    const float* b = &w.lb[8 * (size_t)w.ord[0][(size_t)o]];
+                    for (int k = 0; k < 3; k++) { box[k] = b[k] - box_pad; box[3 + k] = b[4 + k] + box_pad; }
+                    return ~w.lnode[(size_t)w.ord[0][(size_t)o]];
+                }
+                const int room = levels_max - d - 1;
+                const int side_max = room >= 30 ? n : std::min(n, 1 << room);
+                const int k_lo = std::max(1, n - side_max), k_hi = std::min(n - 1, side_max);
+                const __m128 empty_lo = _mm_setr_ps(3e38f, 3e38f, 3e38f, 0.f), empty_hi = _mm_setr_ps(-3e38f, -3e38f, -3e38f, 0.f);
+                auto half_area4 = [](__m128 mn, __m128 mx) {  // x * y + y * z + z * x of the extents, summed left to right
+                    const __m128 e = _mm_sub_ps(mx, mn);
+                    const __m128 p = _mm_mul_ps(e, _mm_shuffle_ps(e, e, _MM_SHUFFLE(3, 0, 2, 1)));
+                    return _mm_cvtss_f32(_mm_add_ss(_mm_add_ss(p, _mm_shuffle_ps(p, p, 1)), _mm_shuffle_ps(p, p, 2)));
+                };
+                const float* lb = w.lb.data();
+                __m128 tlo = empty_lo, thi = empty_hi;
+                for (int k = 0; k < n; k++) {
+                    const float* b = lb + 8 * (size_t)w.ord[0][(size_t)(o + k)];
+                    tlo = _mm_min_ps(_mm_loadu_ps(b), tlo);
+                    thi = _mm_max_ps(_mm_loadu_ps(b + 4), thi);
+                }
+                float t_lo[4], t_hi[4];
+                _mm_storeu_ps(t_lo, tlo);
+                _mm_storeu_ps(t_hi, thi);
+                for (int k = 0; k < 3; k++) { box[k] = t_lo[k] - box_pad; box[3 + k] = t_hi[k] + box_pad; }
+                int best_axis = -1, best_k = -1;
+                float best = 3e38f;
+                for (int axis = 0; axis < 3; axis++) {
+                    const int* so = &w.ord[axis][(size_t)o];
+                    __m128 blo = empty_lo, bhi = empty_hi;
+                    float cw = 0.f;
+                    for (int k = n - 1; k >= 1; k--) {
+                        const float* b = lb + 8 * (size_t)so[k];
+                        blo = _mm_min_ps(_mm_loadu_ps(b), blo);
+                        bhi = _mm_max_ps(_mm_loadu_ps(b + 4), bhi);
+                        cw += w.lcost[(size_t)so[k]];
+                        w.suffix[2 * (size_t)k] = half_area4(blo, bhi);
+                        w.suffix[2 * (size_t)k + 1] = cw;
+                    }
+                    blo = empty_lo;
+                    bhi = empty_hi;
+                    cw = 0.f;
+                    for (int k = 1; k < n; k++) {
+                        const float* b = lb + 8 * (size_t)so[k - 1];
+                        blo = _mm_min_ps(_mm_loadu_ps(b), blo);
+                        bhi = _mm_max_ps(_mm_loadu_ps(b + 4), bhi);
+                        cw += w.lcost[(size_t)so[k - 1]];
+                        if (k < k_lo || k > k_hi) continue;
+                        const float cst = half_area4(blo, bhi) * cw + w.suffix[2 * (size_t)k] * w.suffix[2 * (size_t)k + 1];
+                        if (cst < best) { best = cst; best_axis = axis; best_k = k; }
+                    }
+                }
+                if (best_axis < 0) {  // no admissible surface-area split: halves along the widest axis of the centroids
+                    float ext[3];
+                    for (int a = 0; a < 3; a++)
+                        ext[a] = w.lc[3 * (size_t)w.ord[a][(size_t)(o + n - 1)] + (size_t)a] - w.lc[3 * (size_t)w.ord[a][(size_t)o] + (size_t)a];
+                    best_axis = 0;
+                    for (int a = 1; a < 3; a++)
+                        if (ext[a] > ext[best_axis]) best_axis = a;
+                    best_k = n / 2;
+                }
+                {
+                    const int* so = &w.ord[best_axis][(size_t)o];
+                    for (int k = 0; k < n; k++) w.side[(size_t)so[k]] = (unsigned char)(k < best_k ? 1 : 0);
+                    for (int axis = 0; axis < 3; axis++) {
+                        if (axis == best_axis) continue;
+                        int* oa = &w.ord[axis][(size_t)o];
+                        int nl = 0, nr = 0;
+                        for (int k = 0; k < n; k++) {
+                            const int t = oa[k];
+                            if (w.side[(size_t)t]) oa[nl++] = t;
+                            else w.scratch[(size_t)nr++] = t;
+                        }
+                        memcpy(oa + nl, w.scratch.data(), (size_t)nr * sizeof(int));
+                    }
+                }
+                const int mid = lo + best_k;
+                float ba[6], bb2[6];
+                const int ea = self(self, w, lo, mid, d + 1, ba), eb = self(self, w, mid, hi, d + 1, bb2);
+                ShortNode& nd = shorts[(size_t)mid - 1];
+                memcpy(nd.box[0], ba, sizeof(ba));
+                memcpy(nd.box[1], bb2, sizeof(bb2));
+                nd.e[0] = ea;
+                nd.e[1] = eb;
+                return mid - 1;
+            };
+            const bool short_resort = getenv("RT_SHORT_RESORT") != nullptr;
             // returns the entry of the node over prims[lo, hi) standing at level d (root: 0) and its padded box
             auto build_short = [&](auto&& self, int lo, int hi, int d, float* box) -> int {
                 const int n = hi - lo;
                 int seen = deepest_short.load();
                 while (seen < d && !deepest_short.compare_exchange_weak(seen, d)) {}
+                if (n >= 2 && n <= short_sweep_max && !short_resort) {
+                    ShortSweep w;
+                    sweep_short_begin(w, lo, hi);
+                    return sweep_short(sweep_short, w, lo, hi, d, box);
+                }
                 if (n == 1) {
                     memcpy(box, prims[(size_t)lo].b, 6 * sizeof(float));
                     for (int k = 0; k < 3; k++) { box[k] -= box_pad; box[3 + k] += box_pad; }
@@ -2782,7 +2921,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 need = nk - 1 + below;
                 return idx;
             };
-            std::vector<std::vector<WideNode>> loc((size_t)n_workers_max);
+            std::vector<BigVec<WideNode>> loc((size_t)n_workers_max);
             std::vector<int> task_root(tasks.size(), 0), need_max((size_t)n_workers_max, 0), task_worker(tasks.size(), 0);
             const int nw = par_ranges(tasks.size(), [&](int wi, size_t lo, size_t hi) {
                 // (two-child nodes collapse to about 0.45 wide nodes each; the tasks are spread evenly: no regrowth in the common case)

@@ -86,6 +86,26 @@ def test_presorted_sweep_builds_the_same_sub_trees(rt, monkeypatch, seed, n, dep
     assert np.array_equal(as_int(items_a), as_int(items_b)) and np.array_equal(places_a, places_b)
 
 
+@pytest.mark.parametrize("seed,n,depth,short_sweep_max,runs_max", [(1, 900, 4, None, None), (2, 3000, 16, None, None), (3, 400, 1, None, "0"),
+                                                                    (4, 2500, 2, "16", None), (5, 1500, 0, "100", "0"), (6, 5000, 6, "7", None)])
+def test_presorted_sweep_builds_the_same_shortcut_tree(rt, monkeypatch, seed, n, depth, short_sweep_max, runs_max):
+    """The shortcut tree's builder sorts the leaves of a node of at most RT_SHORT_SWEEP_MAX once per axis and keeps the
+    orders by stable partition (rt_core.hip, sweep_short); RT_SHORT_RESORT selects the form that sorts the records at
+    every node.  Same item stream, byte for byte -- over runs and over the reference's leaves (RT_SHORT_RUNS_MAX=0), and
+    below binned splits (nodes above the sweep bound), where the sweep starts from a partitioned range."""
+    monkeypatch.setenv("RT_SUB_MIN_TRIS", "0")
+    if short_sweep_max:
+        monkeypatch.setenv("RT_SHORT_SWEEP_MAX", short_sweep_max)
+    if runs_max:
+        monkeypatch.setenv("RT_SHORT_RUNS_MAX", runs_max)
+    sc, _ = make_scene(rt, seed, n, depth)
+    info_a, items_a, places_a = rt.device_layout(sc)
+    monkeypatch.setenv("RT_SHORT_RESORT", "1")
+    info_b, items_b, places_b = rt.device_layout(sc)
+    assert info_a.n_wide == info_b.n_wide > 0 and info_a.n_inner == info_b.n_inner and info_a.short_depth == info_b.short_depth
+    assert np.array_equal(as_int(items_a), as_int(items_b)) and np.array_equal(places_a, places_b)
+
+
 @pytest.mark.parametrize("binary", [False, True])
 @pytest.mark.parametrize("seed,n,depth,by_leaves", [(1, 900, 4, False), (2, 3000, 16, False), (3, 400, 1, False), (1, 900, 4, True),
                                                    (2, 3000, 16, True), (4, 200, 3, "single"), (1, 900, 4, "cut2"), (3, 400, 1, "cut3")])
