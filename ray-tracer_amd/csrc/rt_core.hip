@@ -2921,35 +2921,51 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 need = nk - 1 + below;
                 return idx;
             };
-            std::vector<BigVec<WideNode>> loc((size_t)n_workers_max);
-            std::vector<int> task_root(tasks.size(), 0), need_max((size_t)n_workers_max, 0), task_worker(tasks.size(), 0);
-            const int nw = par_ranges(tasks.size(), [&](int wi, size_t lo, size_t hi) {
-                // (two-child nodes collapse to about 0.45 wide nodes each; the tasks are spread evenly: no regrowth in the common case)
-                loc[(size_t)wi].reserve((size_t)((double)subs.size() * 0.5 * (double)(hi - lo) / (double)std::max<size_t>(tasks.size(), 1)) + 64);
-                for (size_t k = lo; k < hi; k++) {
-                    int need = 0;
-                    task_root[k] = collapse_sub(collapse_sub, loc[(size_t)wi], tasks[k].sub, need);
-                    task_worker[k] = wi;
-                    need_max[(size_t)wi] = std::max(need_max[(size_t)wi], need);
-                }
-            });
+            // (in contiguous parts of the task list, several per thread, taken as threads come free; merged in part order: the
+            //  same numbering as one thread's)
+            const int nw = tasks.size() >= 4096 ? 128 : 1;
+            std::vector<BigVec<WideNode>> loc((size_t)nw);
+            std::vector<int> task_root(tasks.size(), 0), need_max((size_t)nw, 0), task_worker(tasks.size(), 0);
+            {
+                std::atomic<int> next{0};
+                auto body = [&] {
+                    for (int wi; (wi = next.fetch_add(1)) < nw;) {
+                        const size_t lo = tasks.size() * (size_t)wi / (size_t)nw, hi = tasks.size() * (size_t)(wi + 1) / (size_t)nw;
+                        // (two-child nodes collapse to about 0.45 wide nodes each; the tasks are spread evenly: no regrowth in the common case)
+                        loc[(size_t)wi].reserve((size_t)((double)subs.size() * 0.5 * (double)(hi - lo) / (double)std::max<size_t>(tasks.size(), 1)) + 64);
+                        for (size_t k = lo; k < hi; k++) {
+                            int need = 0;
+                            task_root[k] = collapse_sub(collapse_sub, loc[(size_t)wi], tasks[k].sub, need);
+                            task_worker[k] = wi;
+                            need_max[(size_t)wi] = std::max(need_max[(size_t)wi], need);
+                        }
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < (nw > 1 ? n_workers_max : 1); t++) th.emplace_back(body);
+                body();
+                for (auto& t : th) t.join();
+            }
             timer.stage("shortcut tree: wide forms of the sub-tree parts (threads)");
             std::vector<size_t> off((size_t)nw + 1, (size_t)n_wide_top);
             for (int wi = 0; wi < nw; wi++) off[(size_t)wi + 1] = off[(size_t)wi] + loc[(size_t)wi].size();
             wides.resize(off[(size_t)nw]);
             {
-                std::vector<std::thread> th;
-                auto copy = [&](int wi) {
-                    const int o = (int)off[(size_t)wi];
-                    for (size_t k = 0; k < loc[(size_t)wi].size(); k++) {
-                        WideNode nd = loc[(size_t)wi][k];
-                        for (int i = 0; i < nd.nk; i++)
-                            if (nd.e[i] >= 0) nd.e[i] += o;
-                        wides[(size_t)o + k] = nd;
+                std::atomic<int> next{0};
+                auto copy = [&] {
+                    for (int wi; (wi = next.fetch_add(1)) < nw;) {
+                        const int o = (int)off[(size_t)wi];
+                        for (size_t k = 0; k < loc[(size_t)wi].size(); k++) {
+                            WideNode nd = loc[(size_t)wi][k];
+                            for (int i = 0; i < nd.nk; i++)
+                                if (nd.e[i] >= 0) nd.e[i] += o;
+                            wides[(size_t)o + k] = nd;
+                        }
                     }
                 };
-                for (int wi = 1; wi < nw; wi++) th.emplace_back(copy, wi);
-                copy(0);
+                std::vector<std::thread> th;
+                for (int t = 1; t < (nw > 1 ? n_workers_max : 1); t++) th.emplace_back(copy);
+                copy();
                 for (auto& t : th) t.join();
             }
             int sub_need = 0;
