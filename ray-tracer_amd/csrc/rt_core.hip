@@ -1612,6 +1612,25 @@ struct HostLayout {
 
 // What does not depend on the layout -- the cold triangle data (the reference's order) and the texture pool, 45 % of a big scene's
 // bytes -- is formed and copied to the device by a thread of its own WHILE build_layout runs (rt_upload_scene only).
+// order[0..n) = the indices 0 .. n-1 sorted by key, ties by index: a byte-wise radix sort from the lowest byte up (each pass
+// is stable, so equal keys keep their index order; a byte that is the same in every key is skipped: the centroids of one
+// leaf share their high bytes).  tmp: n ints of scratch.  The builders' sweeps sort a few hundred keys per leaf, three
+// times: this is 2-3 x faster there than std::sort on (key, index) pairs and gives the same order.
+static void order_by_key32(const uint32_t* key, int n, int* order, int* tmp) {
+    for (int k = 0; k < n; k++) order[k] = k;
+    int *src = order, *dst = tmp;
+    for (int shift = 0; shift < 32; shift += 8) {
+        unsigned cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        for (int k = 0; k < n; k++) cnt[((key[src[k]] >> shift) & 255u) + 1]++;
+        if (n > 0 && cnt[((key[src[0]] >> shift) & 255u) + 1] == (unsigned)n) continue;
+        for (int d = 0; d < 256; d++) cnt[d + 1] += cnt[d];
+        for (int k = 0; k < n; k++) dst[cnt[(key[src[k]] >> shift) & 255u]++] = src[k];
+        std::swap(src, dst);
+    }
+    if (src != order) memcpy(order, src, (size_t)n * sizeof(int));
+}
+
 // The item of the triangle at place p of the item stream (rt_device.h): vertex 0, the two edges, flags, end of its leaf, id, leaf.
 static inline void fill_tri_item(float* h, const float* tris, int tri, unsigned char flags, int leaf_end, int leaf_node) {
     const float* t = tris + (size_t)tri * RT_TRI_FLOATS;
@@ -1847,6 +1866,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
         std::vector<SubNode> subs;
         std::vector<int> sorted, best_sorted;
         std::vector<uint64_t> keys;
+        std::vector<uint32_t> keys32;
         // sweep_sub: the node of at most sweep_max triangles being built: its triangles, their boxes and areas, and per
         // axis the local indices in sorted order (position p of `at` <-> entry p - base)
         int base = 0;
@@ -1985,6 +2005,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
             b[4] = b6[3]; b[5] = b6[4]; b[6] = b6[5]; b[7] = 0.f;
             w.larea[(size_t)k] = tri_area[(size_t)tri];
         }
+        w.keys32.resize((size_t)n);
         for (int axis = 0; axis < 3; axis++) {
             for (int k = 0; k < n; k++) {
                 const int tri = w.ltri[(size_t)k];
@@ -1992,10 +2013,15 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 uint32_t b;
                 memcpy(&b, &cc, 4);
                 b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                w.keys32[(size_t)k] = b;
                 w.keys[(size_t)k] = ((uint64_t)b << 32) | (uint32_t)k;
             }
-            std::sort(w.keys.begin(), w.keys.end());
             w.ord[axis].resize((size_t)n);
+            if (n >= 48) {
+                order_by_key32(w.keys32.data(), n, w.ord[axis].data(), w.scratch.data());
+                continue;
+            }
+            std::sort(w.keys.begin(), w.keys.end());
             for (int k = 0; k < n; k++) w.ord[axis][(size_t)k] = (int)(uint32_t)w.keys[(size_t)k];
         }
     };
@@ -2527,6 +2553,7 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                 std::vector<int> lnode, ord[3], scratch;
                 std::vector<unsigned char> side;
                 std::vector<uint64_t> keys;
+                std::vector<uint32_t> keys32;
             };
             auto ckey = [](float f) {  // the float's bits made monotonic, -0 folded into +0
                 f += 0.0f;
@@ -2551,10 +2578,16 @@ int build_layout(const rt_scene_desc* s, HostLayout& L, std::string& err, Upload
                     w.lnode[(size_t)k] = p.node;
                     for (int c = 0; c < 3; c++) w.lc[3 * (size_t)k + (size_t)c] = p.c[c];
                 }
+                w.keys32.resize((size_t)n);
                 for (int axis = 0; axis < 3; axis++) {
+                    w.ord[axis].resize((size_t)n);
+                    if (n >= 48) {
+                        for (int k = 0; k < n; k++) w.keys32[(size_t)k] = ckey(w.lc[3 * (size_t)k + (size_t)axis]);
+                        order_by_key32(w.keys32.data(), n, w.ord[axis].data(), w.scratch.data());
+                        continue;
+                    }
                     for (int k = 0; k < n; k++) w.keys[(size_t)k] = ((uint64_t)ckey(w.lc[3 * (size_t)k + (size_t)axis]) << 32) | (uint32_t)k;
                     std::sort(w.keys.begin(), w.keys.end());
-                    w.ord[axis].resize((size_t)n);
                     for (int k = 0; k < n; k++) w.ord[axis][(size_t)k] = (int)(uint32_t)w.keys[(size_t)k];
                 }
             };
