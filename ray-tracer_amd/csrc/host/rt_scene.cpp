@@ -507,8 +507,11 @@ struct TmpNode {
 
 // Output stage shared by the builders: nodes are in creation order = BFS order, A before B (BFSIndex,
 // BVHcreator.cpp:41-61); triangles are rewritten leaf by leaf in that order (populateBVHNodes :209-237).
+// owner (optional): the vector whose tail `tris` is (records behind a prefix of owner->size() - n_floats floats).  The
+// reordered records are then written into a fresh vector that takes the owner's place, instead of into a scratch array
+// that is copied back (1 GB each way for 10 M triangles).
 int finish_bvh(const std::vector<TmpNode>& nodes, const uint32_t* ids, float* tris, size_t n_floats,
-               std::vector<rt_bvh_node>& out, int* out_depth) {
+               std::vector<rt_bvh_node>& out, int* out_depth, FloatVec* owner = nullptr) {
     StageTimer tm_out("bvh: numbering + reorder");
     out.resize(nodes.size());
     int offs = 0, deepest_leaf = 0;
@@ -522,6 +525,22 @@ int finish_bvh(const std::vector<TmpNode>& nodes, const uint32_t* ids, float* tr
         o.tri_len = n.a < 0 ? (int)(n.end - n.begin) * RT_TRI_FLOATS : 0;
         offs += o.tri_len;
         if (n.a < 0) deepest_leaf = std::max(deepest_leaf, n.depth);
+    }
+    if (owner && owner->size() >= n_floats && owner->data() + (owner->size() - n_floats) == tris) {
+        const size_t prefix = owner->size() - n_floats;
+        FloatVec fresh(owner->size());  // (not zero-filled: every float is written below)
+        if (prefix) memcpy(fresh.data(), owner->data(), prefix * sizeof(float));
+        float* base = fresh.data() + prefix;
+        parallel_for(nodes.size(), 64, [&](size_t k) {
+            const TmpNode& n = nodes[k];
+            if (n.a >= 0) return;
+            float* dst = base + (size_t)out[k].tri_offs;
+            for (uint32_t i = n.begin; i < n.end; i++, dst += RT_TRI_FLOATS)
+                memcpy(dst, tris + (size_t)ids[i] * RT_TRI_FLOATS, RT_TRI_FLOATS * sizeof(float));
+        });
+        owner->swap(fresh);
+        if (out_depth) *out_depth = deepest_leaf;
+        return RT_OK;
     }
     BigBuf<float> newtris = big_buf<float>(std::max<size_t>(n_floats, 1));  // (not zero-filled: every float is written below)
     parallel_for(nodes.size(), 64, [&](size_t k) {
@@ -551,7 +570,7 @@ int finish_bvh(const std::vector<TmpNode>& nodes, const uint32_t* ids, float* tr
 //    chunks (min/max are exact, so chunking cannot change a box);
 //  * children are created A then B in parent order, which IS the reference's BFS numbering.
 int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::vector<rt_bvh_node>& out,
-              int* out_depth) {
+              int* out_depth, FloatVec* owner = nullptr) {
     if (n_floats % RT_TRI_FLOATS != 0) return fail("triangle array length is not a multiple of 25");
     const size_t ntri = n_floats / RT_TRI_FLOATS;
     if (ntri > 0x7fffffffu / RT_TRI_FLOATS) return fail("too many triangles for int32 float offsets");
@@ -771,7 +790,7 @@ int build_bvh(float* tris, size_t n_floats, int max_depth, int min_tris, std::ve
         const uint32_t* orig = orig_mem.get();
         parallel_for(ntri, 1 << 16, [&](size_t j) { ids[j] = orig[ids[j]]; });
     }
-    return finish_bvh(nodes, ids, tris, n_floats, out, out_depth);
+    return finish_bvh(nodes, ids, tris, n_floats, out, out_depth, owner);
 }
 
 // NON-PARITY fast mode: a binned-SAH BVH2 in the same node / triangle layout, leaves of at most
@@ -1166,7 +1185,7 @@ int finish_geometry(rt_host_scene* sc, FloatVec& records, int max_depth, int min
         if (!records.empty()) memcpy(sc->tris.data() + prefix, records.data(), records.size() * sizeof(float));
     }
     FloatVec().swap(records);
-    int rc = build_bvh(sc->tris.data() + prefix, sc->tris.size() - prefix, max_depth, min_tris, sc->nodes, &sc->bvh_depth);
+    int rc = build_bvh(sc->tris.data() + prefix, sc->tris.size() - prefix, max_depth, min_tris, sc->nodes, &sc->bvh_depth, &sc->tris);
     if (rc != RT_OK) return rc;
     extract_lights(sc->tris.data() + prefix, sc->tris.size() - prefix, sc->lights);
     return RT_OK;
